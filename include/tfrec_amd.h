@@ -1,0 +1,188 @@
+/*
+ * tfrec_amd -- C ABI of the MI355X-native matrix-factorization ranking path.
+ *
+ * One shared library (libtfrec_amd.so), plain pointers and sizes, no C++ or
+ * framework types.  Every entry point returns 0 on success and a negative
+ * TFREC_E* code on failure; tfrec_last_error() then holds a message for the
+ * calling thread.  Nothing throws across this boundary.
+ *
+ * Conventions
+ *   - "d_" parameters are device pointers on the context's GPU, "h_" are host
+ *     pointers.  Tables are row-major float32: P [U,d], Q [I,d], b [I].
+ *   - The caller owns every buffer it passes.  The context owns only its own
+ *     workspace (grown on demand, or up front with tfrec_ctx_reserve) and its
+ *     HIP stream handle (borrowed when one is passed in).
+ *   - Work is enqueued on the context's stream and is asynchronous unless a host
+ *     output is produced; tfrec_ctx_synchronize() waits and reports the sticky
+ *     device-side error flags (e.g. an index out of range in a batch).
+ *   - A context is not re-entrant: one thread at a time per context.
+ *
+ * Each declaration names the reference interface it replaces (file:line in the
+ * reference tree).
+ */
+#ifndef TFREC_AMD_H
+#define TFREC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFREC_ABI_VERSION 1
+
+#define TFREC_OK 0
+#define TFREC_EINVAL (-1)   /* bad argument (shape, alignment, null pointer)            */
+#define TFREC_EHIP (-2)     /* a HIP runtime call failed                                */
+#define TFREC_ENOMEM (-3)   /* device or host allocation failed                         */
+#define TFREC_EINDEX (-4)   /* a user/item index in a batch was out of range            */
+#define TFREC_EUNSUP (-5)   /* unsupported configuration (e.g. d too large, k too large) */
+
+/* device-side sticky flags reported by tfrec_ctx_error_flags() */
+#define TFREC_FLAG_BAD_INDEX 1u
+
+typedef struct tfrec_ctx tfrec_ctx;
+
+/* ---- library / context ------------------------------------------------------------------ */
+/* Replaces nothing in the reference: errors there are Python exceptions
+ * (evaluator/backend/cpp/apt_evaluate.pyx:21-22, utils/tools.py:21). */
+const char *tfrec_last_error(void);
+int tfrec_abi_version(void);
+
+/* The reference's device context is the tf.Session made in run_model.py:14-16.
+ * hip_stream may be NULL (the context then creates and owns a stream) or a hipStream_t
+ * owned by the caller (e.g. torch's current stream). */
+int tfrec_ctx_create(int device, void *hip_stream, tfrec_ctx **out);
+int tfrec_ctx_destroy(tfrec_ctx *ctx);
+int tfrec_ctx_set_stream(tfrec_ctx *ctx, void *hip_stream);
+void *tfrec_ctx_stream(tfrec_ctx *ctx);
+int tfrec_ctx_synchronize(tfrec_ctx *ctx);                    /* waits; TFREC_EINDEX if a flag is set */
+int tfrec_ctx_error_flags(tfrec_ctx *ctx, uint32_t *h_flags, int clear);
+/* Pre-size the workspace for training batches up to max_batch triples at factor size d and
+ * evaluation of up to max_eval_users users at top-k k, so that later calls allocate nothing. */
+int tfrec_ctx_reserve(tfrec_ctx *ctx, int64_t max_batch, int d, int64_t max_eval_users, int k);
+int64_t tfrec_ctx_workspace_bytes(tfrec_ctx *ctx);
+
+/* ---- device memory helpers (for callers without their own allocator) --------------------- */
+int tfrec_dev_malloc(tfrec_ctx *ctx, size_t bytes, void **d_ptr);
+int tfrec_dev_free(tfrec_ctx *ctx, void *d_ptr);
+int tfrec_memcpy_h2d(tfrec_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);   /* synchronous */
+int tfrec_memcpy_d2h(tfrec_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);   /* synchronous */
+int tfrec_memset_zero(tfrec_ctx *ctx, void *d_dst, size_t bytes);
+
+/* ---- parameters --------------------------------------------------------------------------- */
+/* model/base/MatrixFactorization.py:17-21: tables ~ U(lo, hi) (reference: -0.05, 0.05), bias 0.
+ * Counter-based generator: element n gets the n-th value of the stream named by seed. */
+int tfrec_fill_uniform(tfrec_ctx *ctx, float *d_x, int64_t n, float lo, float hi, uint64_t seed);
+int tfrec_fill_const(tfrec_ctx *ctx, float *d_x, int64_t n, float value);
+
+/* model/base/MatrixFactorization.py:26-32 (predict): out[t] = <P[users[t]], Q[items[t]]> + b[items[t]] */
+int tfrec_mf_predict(tfrec_ctx *ctx, const float *d_P, const float *d_Q, const float *d_b,
+                     int64_t U, int64_t I, int d,
+                     const int32_t *d_users, const int32_t *d_items, int64_t n, float *d_out);
+
+/* ---- training steps ------------------------------------------------------------------------ */
+/* One BPR-MF minibatch step with plain SGD: the graph of model/BPR.py:36-48 (identical in
+ * model/DNSBPR.py:35-47) executed by sess.run(self.update) at model/BPR.py:72.
+ *   loss = sum_t -log_sigmoid(y(u,i)-y(u,j)+1e-7) + reg * l2(gathered rows and biases)
+ * All gradients are taken at the pre-step parameters; a row that occurs n times in the batch
+ * receives the sum of its n per-occurrence gradients (duplicates reduced without atomics, in a
+ * fixed order: results are bitwise reproducible).  d_loss, if not NULL, receives two doubles:
+ * the rank loss and the un-scaled l2 term. */
+int tfrec_bpr_sgd_step(tfrec_ctx *ctx, float *d_P, float *d_Q, float *d_b,
+                       int64_t U, int64_t I, int d,
+                       const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg, int64_t B,
+                       float lr, float reg, double *d_loss);
+
+/* One APR minibatch step: both session calls of model/APR.py:163-164.
+ *   1) delta <- eps * l2_normalize(d L_bpr / d Theta)   (model/APR.py:116-132; rows one by one,
+ *      the bias gradient as one vector over all items)
+ *   2) sparse Adagrad (accumulators start at 0.1 in the reference) on
+ *      L + reg_adv * L(Theta+delta) + 2*reg*mean(p^2+q_i^2+q_j^2+b_i^2+b_j^2)  (model/APR.py:86-114,134-136)
+ * d_dP/d_dQ/d_db are the delta tables of model/APR.py:55-60 (same shapes as P/Q/b); only the
+ * rows of the batch are written and read.  d_loss (nullable) receives three doubles:
+ * L, L_adv and the mean-square term. */
+int tfrec_apr_adagrad_step(tfrec_ctx *ctx, float *d_P, float *d_Q, float *d_b,
+                           float *d_accP, float *d_accQ, float *d_accb,
+                           float *d_dP, float *d_dQ, float *d_db,
+                           int64_t U, int64_t I, int d,
+                           const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg, int64_t B,
+                           float lr, float reg, float reg_adv, float eps, double *d_loss);
+
+/* DNS-BPR candidate selection, model/DNSBPR.py:74-79: for positive t with user d_users[t] and
+ * candidates d_cand[t*C .. t*C+C), out_neg[t] = the candidate with the largest score
+ * <P[u],Q[c]> + b[c]; the first maximum wins.  Only the C sampled rows are read (the reference
+ * scores all items per user, model/DNSBPR.py:68-70, and then indexes the pool). */
+int tfrec_dns_select(tfrec_ctx *ctx, const float *d_P, const float *d_Q, const float *d_b,
+                     int64_t U, int64_t I, int d,
+                     const int32_t *d_users, const int32_t *d_cand, int64_t n_pos, int C,
+                     int32_t *d_out_neg);
+
+/* ---- evaluation ---------------------------------------------------------------------------- */
+#define TFREC_SCORE_F32 0    /* exact float32: score = fma chain over f ascending, starting at b[i] */
+#define TFREC_SCORE_BF16 1   /* operands rounded to bfloat16, float32 accumulation (MFMA)            */
+
+/* Scoring + top-k in factor form, never forming the dense [users, items] matrix that
+ * model/BPR.py:76-80 (_predict) builds and evaluator/backend/cpp/evaluate.py:25-27 masks:
+ * for each listed user, score items [item_lo, item_hi) of Q/b (rows item_lo.. of the full
+ * tables), skip the user's train items (CSR over all users, sorted rows; may be NULL) and
+ * keep the k best under the total order (score descending, item id ascending).
+ * Outputs [n,k]: ids are GLOBAL item ids; unused slots (fewer than k candidates in the shard)
+ * hold id -1 and score -inf.  This is one item shard's work in a multi-GPU evaluation. */
+int tfrec_score_topk(tfrec_ctx *ctx, const float *d_P, const float *d_Q, const float *d_b,
+                     int64_t I, int d, int64_t item_lo, int64_t item_hi,
+                     const int32_t *d_eval_users, int64_t n,
+                     const int64_t *d_train_indptr, const int32_t *d_train_indices,
+                     int k, int score_mode, int32_t *d_out_ids, float *d_out_scores);
+
+/* Merge G per-shard top-k lists [G,n,k] into the global top-k [n,k] under the same total
+ * order (the all-gather merge of an item-sharded evaluation). */
+int tfrec_topk_merge(tfrec_ctx *ctx, const int32_t *d_ids, const float *d_scores, int G, int64_t n, int k,
+                     int32_t *d_out_ids, float *d_out_scores);
+
+/* If a user has fewer than k rankable (non-train) items the reference's ranking continues into
+ * its -inf masked train items (evaluator/backend/cpp/evaluate.py:27 + tools.h:17); this fills
+ * ids still -1 with that user's train items in ascending id order. */
+int tfrec_topk_fill_masked(tfrec_ctx *ctx, int32_t *d_ids, const int32_t *d_eval_users, int64_t n, int k,
+                           const int64_t *d_train_indptr, const int32_t *d_train_indices);
+
+/* Replaces c_top_k_array_index (evaluator/backend/cpp/tools.h:22-30) on a dense row-major
+ * [rows, cols] float32 matrix already on the device: ids of the k best of every row, total
+ * order (score descending, id ascending).  If mask CSR is given, row r's listed columns are
+ * treated as -inf (evaluator/backend/cpp/evaluate.py:25-27) without touching the matrix;
+ * d_mask_rows maps matrix row -> CSR row (NULL = identity). */
+int tfrec_topk_dense(tfrec_ctx *ctx, const float *d_ratings, int64_t rows, int64_t cols, int k,
+                     const int32_t *d_mask_rows, const int64_t *d_mask_indptr, const int32_t *d_mask_indices,
+                     int32_t *d_out_ids, float *d_out_scores);
+
+/* Replaces evaluate (evaluator/backend/cpp/evaluate.h:13-93) and the five curves of
+ * evaluator/backend/cpp/metrics.h:11-100: from rank lists [n,k] and the ground truth CSR
+ * (row of user d_eval_users[r]; sorted rows) compute Precision/Recall/MAP/NDCG/MRR @1..k per
+ * user and their mean over the n users.  h_mean [5,k] float32 (fully overwritten; no
+ * pre-zeroing contract).  d_per_user [n,5,k] is optional (NULL to skip).
+ * mean_mode 0: deterministic float64 tree sum on the device; 1: per-user rows are brought to
+ * the host and summed sequentially in float32 in user order, which is bit-for-bit what
+ * evaluate.h:40-92 does. */
+int tfrec_rank_metrics(tfrec_ctx *ctx, const int32_t *d_ids, const int32_t *d_eval_users, int64_t n, int k,
+                       const int64_t *d_test_indptr, const int32_t *d_test_indices,
+                       int mean_mode, float *d_per_user, float *h_mean);
+/* Same, but leaves the [5,k] float64 SUMS over the n users on the device (no host sync), for
+ * callers that reduce across GPUs before dividing. */
+int tfrec_rank_metrics_sums(tfrec_ctx *ctx, const int32_t *d_ids, const int32_t *d_eval_users, int64_t n, int k,
+                            const int64_t *d_test_indptr, const int32_t *d_test_indices,
+                            float *d_per_user, double *d_sums);
+
+/* All of the above in one call for one GPU: what FoldOutEvaluator.evaluate
+ * (evaluator/evaluator.py:29-32) returns, from the factors. */
+int tfrec_eval_fullrank(tfrec_ctx *ctx, const float *d_P, const float *d_Q, const float *d_b,
+                        int64_t I, int d, const int32_t *d_eval_users, int64_t n,
+                        const int64_t *d_train_indptr, const int32_t *d_train_indices,
+                        const int64_t *d_test_indptr, const int32_t *d_test_indices,
+                        int k, int score_mode, int mean_mode,
+                        int32_t *d_out_ids /* [n,k] or NULL */, float *h_mean /* [5,k] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFREC_AMD_H */

@@ -1,0 +1,201 @@
+"""GPU parity tests of full-rank evaluation: fused MFMA scoring + top-k, dense top-k, merge and
+metrics (through the C ABI) against the golden vectors of the reference's own C++ evaluator and
+against the CPU oracle.  Rank lists and hit patterns must match exactly; metric means exactly in
+the reference-order float32 mode and within 1e-6 in the float64 mode."""
+import numpy as np
+import pytest
+
+from conftest import csr_from_pairs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from tfrec_amd.device import Device
+    d = Device(0)
+    yield d
+    d.close()
+
+
+def dcsr(dev, indptr, indices):
+    return dev.array(indptr, np.int64), dev.array(indices, np.int32)
+
+
+def test_ml100k_known_answer(dev, golden_ml100k):
+    g = golden_ml100k
+    U, I = g["P"].shape[0], g["Q"].shape[0]
+    tr = csr_from_pairs(g["train_u"], g["train_i"], U, I)
+    te = csr_from_pairs(g["test_u"], g["test_i"], U, I)
+    P, Q, b = dev.array(g["P"]), dev.array(g["Q"]), dev.array(g["b"])
+    users = dev.array(g["test_users"], np.int32)
+    train, test = dcsr(dev, tr.indptr, tr.indices), dcsr(dev, te.indptr, te.indices)
+    ids = dev.empty((len(g["test_users"]), 50), np.int32)
+    m_ref_order = dev.eval_fullrank(P, Q, b, users, train, test, 50, mean_mode=1, out_ids=ids)
+    assert np.array_equal(ids.numpy(), g["ranks"].astype(np.int32))
+    assert np.array_equal(m_ref_order, g["metrics"])          # bit for bit the reference's float32 means
+    m = dev.eval_fullrank(P, Q, b, users, train, test, 50, mean_mode=0)
+    np.testing.assert_allclose(m, g["metrics"], rtol=1e-6, atol=1e-7)
+    assert abs(m[0, 0] - 0.61220044) < 1e-6 and abs(m[3, 49] - 0.33114389) < 1e-6
+
+
+@pytest.mark.parametrize("case", ["small", "subset", "short_truth", "neg_inf_tail", "c1_shape"])
+def test_eval_cases_factor_form(dev, golden_eval, case):
+    g = {k.split("/", 1)[1]: v for k, v in golden_eval.items() if k.startswith(case + "/")}
+    P, Q, b = dev.array(g["P"]), dev.array(g["Q"]), dev.array(g["b"])
+    users = dev.array(g["test_users"], np.int32)
+    train, test = dcsr(dev, g["train_indptr"], g["train_indices"]), dcsr(dev, g["test_indptr"], g["test_indices"])
+    for k in g["k_list"]:
+        k = int(k)
+        ids = dev.empty((len(g["test_users"]), k), np.int32)
+        m = dev.eval_fullrank(P, Q, b, users, train, test, k, mean_mode=1, out_ids=ids)
+        got, ref = ids.numpy(), g["ranks_k%d" % k]
+        if case == "neg_inf_tail":
+            for r, u in enumerate(g["test_users"]):
+                row = g["train_indices"][g["train_indptr"][u]:g["train_indptr"][u + 1]]
+                n_fin = min(g["Q"].shape[0] - len(row), k)
+                assert np.array_equal(got[r, :n_fin], ref[r, :n_fin])
+                assert np.array_equal(got[r, n_fin:], row[:k - n_fin])     # masked tail: train items, ascending
+        else:
+            assert np.array_equal(got, ref)
+        assert np.array_equal(m, g["metrics_k%d" % k])
+
+
+@pytest.mark.parametrize("case", ["small", "subset", "neg_inf_tail"])
+def test_dense_topk_and_metrics(dev, golden_eval, oracle, case):
+    """The dense drop-in path: c_top_k_array_index + evaluate replacements."""
+    g = {k.split("/", 1)[1]: v for k, v in golden_eval.items() if k.startswith(case + "/")}
+    R = (g["P"] @ g["Q"].T + g["b"]).astype(np.float32)
+    users = g["test_users"]
+    dR = dev.array(R[users])
+    mask = dcsr(dev, g["train_indptr"], g["train_indices"])
+    test = dcsr(dev, g["test_indptr"], g["test_indices"])
+    du = dev.array(users, np.int32)
+    for k in g["k_list"]:
+        k = int(k)
+        ids, scores = dev.topk_dense(dR, k, mask=mask, mask_rows=du)
+        got, ref = ids.numpy(), g["ranks_k%d" % k]
+        if case == "neg_inf_tail":
+            dev.topk_fill_masked(ids, du, k, mask)
+            fin = scores.numpy() > -np.inf
+            assert np.array_equal(got[fin], ref[fin])
+        else:
+            assert np.array_equal(got, ref)
+            sc = scores.numpy()
+            assert np.array_equal(sc, np.take_along_axis(R[users], got, axis=1))
+        m = dev.rank_metrics(ids, du, k, test, mean_mode=1)
+        assert np.array_equal(m, g["metrics_k%d" % k])
+
+
+def test_f32_scores_are_the_fma_chain(dev, oracle):
+    """TFREC_SCORE_F32 is bit-for-bit acc=b; acc=fmaf(p[f],q[f],acc) for f ascending."""
+    rng = np.random.default_rng(9)
+    for (U, I, d, k) in [(70, 3000, 64, 100), (33, 1000, 20, 10), (40, 777, 128, 50), (10, 300, 7, 5)]:
+        P = rng.normal(size=(U, d)).astype(np.float32); Q = rng.normal(size=(I, d)).astype(np.float32)
+        b = rng.normal(size=I).astype(np.float32)
+        users = np.arange(U, dtype=np.int32)
+        ids, scores = dev.score_topk(dev.array(P), dev.array(Q), dev.array(b), dev.array(users), k)
+        ids, scores = ids.numpy(), scores.numpy()
+        for u in range(U):
+            row = oracle.score_row(P[u], Q, b, mode=1)
+            ref = oracle.topk_row(row, k)
+            assert np.array_equal(ids[u], ref), (U, I, d, k, u)
+            assert np.array_equal(scores[u], row[ref])
+
+
+def test_ties_break_by_ascending_id(dev):
+    U, I, d, k = 5, 600, 8, 20
+    P = np.ones((U, d), np.float32); Q = np.zeros((I, d), np.float32); b = np.zeros(I, np.float32)
+    b[100:140] = 1.0                      # forty equal best scores
+    ids, _ = dev.score_topk(dev.array(P), dev.array(Q), dev.array(b), dev.array(np.arange(U, dtype=np.int32)), k)
+    assert np.array_equal(ids.numpy(), np.tile(np.arange(100, 120, dtype=np.int32), (U, 1)))
+    R = np.tile(b, (U, 1))
+    ids2, _ = dev.topk_dense(dev.array(R), k)
+    assert np.array_equal(ids2.numpy(), ids.numpy())
+
+
+def test_item_sharded_merge_equals_single_pass(dev):
+    rng = np.random.default_rng(4)
+    U, I, d, k, G = 300, 9000, 64, 100, 3
+    P = rng.normal(size=(U, d)).astype(np.float32); Q = rng.normal(size=(I, d)).astype(np.float32)
+    b = rng.normal(size=I).astype(np.float32)
+    indptr = np.arange(0, 20 * (U + 1), 20, dtype=np.int64)
+    indices = np.concatenate([np.sort(rng.choice(I, 20, replace=False)) for _ in range(U)]).astype(np.int32)
+    dP, dQ, db = dev.array(P), dev.array(Q), dev.array(b)
+    users = dev.array(np.arange(U, dtype=np.int32))
+    train = dcsr(dev, indptr, indices)
+    full_ids, full_sc = dev.score_topk(dP, dQ, db, users, k, train=train)
+    bounds = [0, 2500, 2500, 9000]       # includes an empty shard
+    ids_all = dev.empty((G, U, k), np.int32); sc_all = dev.empty((G, U, k), np.float32)
+    hi, hs = [], []
+    for gi in range(G):
+        a, s = dev.score_topk(dP, dQ, db, users, k, train=train, item_range=(bounds[gi], bounds[gi + 1]))
+        hi.append(a.numpy()); hs.append(s.numpy())
+    ids_all.copy_from(np.stack(hi)); sc_all.copy_from(np.stack(hs))
+    mi, ms = dev.topk_merge(ids_all, sc_all, G, U, k)
+    assert np.array_equal(mi.numpy(), full_ids.numpy()) and np.array_equal(ms.numpy(), full_sc.numpy())
+    got = full_ids.numpy()
+    for u in range(U):
+        assert not set(got[u]) & set(indices[indptr[u]:indptr[u + 1]])
+
+
+def test_few_users_many_items_uses_item_splits(dev, oracle):
+    rng = np.random.default_rng(6)
+    U, I, d, k = 7, 40000, 32, 50
+    P = rng.normal(size=(U, d)).astype(np.float32); Q = rng.normal(size=(I, d)).astype(np.float32)
+    b = rng.normal(size=I).astype(np.float32)
+    ids, sc = dev.score_topk(dev.array(P), dev.array(Q), dev.array(b), dev.array(np.arange(U, dtype=np.int32)), k)
+    for u in range(U):
+        row = oracle.score_row(P[u], Q, b, mode=1)
+        assert np.array_equal(ids.numpy()[u], oracle.topk_row(row, k))
+
+
+def test_bf16_scoring(dev, oracle):
+    rng = np.random.default_rng(8)
+    U, I, d, k = 200, 5000, 128, 100
+    P = rng.normal(size=(U, d)).astype(np.float32); Q = rng.normal(size=(I, d)).astype(np.float32)
+    b = rng.normal(size=I).astype(np.float32)
+    from tfrec_amd.device import SCORE_BF16
+    ids, sc = dev.score_topk(dev.array(P), dev.array(Q), dev.array(b), dev.array(np.arange(U, dtype=np.int32)), k, mode=SCORE_BF16)
+    ids, sc = ids.numpy(), sc.numpy()
+    agree = 0
+    for u in range(U):
+        row = oracle.score_row(P[u], Q, b, mode=2)           # bf16-rounded operands, exact accumulation
+        # scores: float32 accumulation of exact bf16 products -> 1e-5 relative to the row's magnitude
+        np.testing.assert_allclose(sc[u], row[ids[u]], rtol=0, atol=2e-5 * np.abs(row).max())
+        ref = oracle.topk_row(row, k)
+        agree += len(set(ref.tolist()) & set(ids[u].tolist()))
+        # wherever the reference ranking has a clear margin the id must agree position by position
+        gaps = -np.diff(row[ref])
+        clear = np.concatenate([[True], gaps > 1e-4]) & np.concatenate([gaps > 1e-4, [True]])
+        assert np.array_equal(ids[u][clear], ref[clear])
+    assert agree >= 0.999 * U * k
+
+
+def test_large_shape_properties(dev):
+    """Size-independent checks at a size the oracle would not finish quickly."""
+    rng = np.random.default_rng(10)
+    U, I, d, k = 20000, 60000, 64, 100
+    P = dev.uniform((U, d), -0.5, 0.5, 1); Q = dev.uniform((I, d), -0.5, 0.5, 2); b = dev.uniform((I,), -0.1, 0.1, 3)
+    users = np.sort(rng.choice(U, 5000, replace=False)).astype(np.int32)
+    deg = 30
+    indptr = np.arange(0, deg * (U + 1), deg, dtype=np.int64)
+    indices = np.sort(rng.integers(0, I, (U, deg)), axis=1).astype(np.int32).ravel()
+    train = dcsr(dev, indptr, indices)
+    ids, sc = dev.score_topk(P, Q, b, dev.array(users), k, train=train)
+    ids, sc = ids.numpy(), sc.numpy()
+    assert (np.diff(sc, axis=1) <= 0).all()                    # sorted
+    assert (ids >= 0).all() and (ids < I).all()
+    srt = np.sort(ids, axis=1)
+    assert (np.diff(srt, axis=1) > 0).all()                    # no duplicates
+    Ph, Qh, bh = P.numpy(), Q.numpy(), b.numpy()
+    for r in rng.choice(len(users), 40, replace=False):
+        u = users[r]
+        row = (Ph[u].astype(np.float64) @ Qh.T.astype(np.float64)) + bh
+        row[indices[indptr[u]:indptr[u + 1]]] = -np.inf
+        best = np.argsort(-row, kind="stable")[:k]
+        gaps = -np.diff(row[best])
+        if gaps.min() > 1e-5:
+            assert np.array_equal(ids[r], best)
+        assert abs(sc[r, -1] - row[best[-1]]) < 1e-5
+        assert not set(ids[r]) & set(indices[indptr[u]:indptr[u + 1]])

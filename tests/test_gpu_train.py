@@ -1,0 +1,196 @@
+"""GPU parity tests of the training steps: HIP path (through the C ABI) against the CPU oracle
+and the committed golden vectors.  Tolerances: post-step parameters and losses within 1e-5
+relative (float32 path vs the float64 oracle); selected indices exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-5, 2e-7
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from tfrec_amd.device import Device
+    d = Device(0)
+    yield d
+    d.close()
+
+
+def run_bpr(dev, P, Q, b, u, i, j, lr, reg, want_loss=True):
+    dP, dQ, db = dev.array(P), dev.array(Q), dev.array(b)
+    du, di, dj = dev.array(u, np.int32), dev.array(i, np.int32), dev.array(j, np.int32)
+    loss = dev.zeros(2, np.float64) if want_loss else None
+    dev.bpr_sgd_step(dP, dQ, db, du, di, dj, lr, reg, loss)
+    dev.synchronize()
+    return dP.numpy(), dQ.numpy(), db.numpy(), (loss.numpy() if want_loss else None)
+
+
+BPR_CASES = ["b1", "b7", "b128", "b512", "b512dup", "d10"]
+
+
+@pytest.mark.parametrize("name", BPR_CASES)
+def test_bpr_step_golden(dev, golden_steps, name):
+    g = golden_steps
+    P, Q, b = [g["bpr_%s_%s" % (name, k)] for k in "PQb"]
+    P1, Q1, b1, loss = run_bpr(dev, P, Q, b, g["bpr_%s_u" % name], g["bpr_%s_i" % name], g["bpr_%s_j" % name], 0.01, 0.05)
+    np.testing.assert_allclose(P1, g["bpr_%s_P1" % name], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(Q1, g["bpr_%s_Q1" % name], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(b1, g["bpr_%s_b1" % name], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(loss, g["bpr_%s_loss" % name], rtol=RTOL)
+
+
+def zipf_ids(rng, n, size, a=1.0):
+    w = 1.0 / np.arange(1, n + 1) ** a
+    return rng.permutation(n)[rng.choice(n, size=size, p=w / w.sum())]
+
+
+@pytest.mark.parametrize("U,I,d,B,kind", [
+    (500, 400, 64, 4096, "uniform"),
+    (500, 400, 128, 3000, "uniform"),
+    (64, 48, 20, 5000, "uniform"),          # every row repeated ~100 times
+    (3000, 2000, 64, 30000, "zipf"),        # hot items: chains of partials longer than one workgroup walks alone
+    (5, 7, 32, 20000, "uniform"),           # a handful of rows, thousands of occurrences each
+    (300, 200, 10, 777, "uniform"),         # d not a multiple of 4: scalar row path
+    (300, 200, 256, 600, "uniform"),
+    (1, 2, 8, 300, "uniform"),
+])
+def test_bpr_step_vs_oracle(dev, oracle, U, I, d, B, kind):
+    rng = np.random.default_rng(U * 7 + B)
+    P = rng.uniform(-0.3, 0.3, (U, d)).astype(np.float32)
+    Q = rng.uniform(-0.3, 0.3, (I, d)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, I).astype(np.float32)
+    u = rng.integers(0, U, B).astype(np.int32)
+    if kind == "zipf":
+        i = zipf_ids(rng, I, B).astype(np.int32)
+        j = rng.integers(0, I, B).astype(np.int32)
+    else:
+        i = rng.integers(0, I, B).astype(np.int32)
+        j = rng.integers(0, I, B).astype(np.int32)
+    Po, Qo, bo = P.copy(), Q.copy(), b.copy()
+    rank, regl = oracle.bpr_step(Po, Qo, bo, u, i, j, 0.01, 0.05)
+    P1, Q1, b1, loss = run_bpr(dev, P, Q, b, u, i, j, 0.01, 0.05)
+    # tolerances are relative to the size of the UPDATE for heavily repeated rows: compare increments
+    for new, ref, old in ((P1, Po, P), (Q1, Qo, Q), (b1, bo, b)):
+        scale = max(np.abs(ref - old).max(), 1e-3)
+        assert np.abs(new - ref).max() <= 1e-5 * scale + 2e-7 * np.abs(ref).max()
+    np.testing.assert_allclose(loss, [rank, regl], rtol=1e-5)
+    # without the loss output the same parameters come out, bit for bit
+    P2, Q2, b2, _ = run_bpr(dev, P, Q, b, u, i, j, 0.01, 0.05, want_loss=False)
+    assert np.array_equal(P1, P2) and np.array_equal(Q1, Q2) and np.array_equal(b1, b2)
+
+
+def test_bpr_step_is_reproducible(dev):
+    rng = np.random.default_rng(3)
+    U, I, d, B = 200, 100, 64, 50000
+    P = rng.uniform(-0.3, 0.3, (U, d)).astype(np.float32)
+    Q = rng.uniform(-0.3, 0.3, (I, d)).astype(np.float32)
+    b = np.zeros(I, np.float32)
+    u, i, j = [rng.integers(0, n, B).astype(np.int32) for n in (U, I, I)]
+    a = run_bpr(dev, P, Q, b, u, i, j, 0.01, 0.05)
+    c = run_bpr(dev, P, Q, b, u, i, j, 0.01, 0.05)
+    for x, y in zip(a, c):
+        assert np.array_equal(x, y)
+
+
+def test_bpr_empty_batch_and_bad_index(dev):
+    P = np.ones((4, 8), np.float32); Q = np.ones((5, 8), np.float32); b = np.zeros(5, np.float32)
+    e = np.zeros(0, np.int32)
+    P1, Q1, b1, loss = run_bpr(dev, P, Q, b, e, e, e, 0.1, 0.1)
+    assert np.array_equal(P1, P) and np.array_equal(Q1, Q) and loss.tolist() == [0.0, 0.0]
+    dP, dQ, db = dev.array(P), dev.array(Q), dev.array(b)
+    dev.bpr_sgd_step(dP, dQ, db, dev.array([0, 9], np.int32), dev.array([1, 1], np.int32), dev.array([2, 2], np.int32), 0.1, 0.1)
+    with pytest.raises(IndexError):
+        dev.synchronize()
+    dev.synchronize()       # the flag is cleared once reported
+    with pytest.raises(NotImplementedError):
+        big = dev.zeros((2, 2048), np.float32)
+        dev.bpr_sgd_step(big, big, db, dev.array([0], np.int32), dev.array([0], np.int32), dev.array([1], np.int32), 0.1, 0.1)
+
+
+def run_apr(dev, P, Q, b, u, i, j, lr, reg, reg_adv, eps):
+    arrs = [dev.array(x) for x in (P, Q, b)]
+    accs = [dev.full(x.shape, 0.1) for x in (P, Q, b)]
+    dels = [dev.zeros(x.shape) for x in (P, Q, b)]
+    loss = dev.zeros(3, np.float64)
+    dev.apr_adagrad_step(*arrs, *accs, *dels, dev.array(u, np.int32), dev.array(i, np.int32), dev.array(j, np.int32),
+                         lr, reg, reg_adv, eps, loss)
+    dev.synchronize()
+    return [x.numpy() for x in arrs], [x.numpy() for x in accs], [x.numpy() for x in dels], loss.numpy()
+
+
+@pytest.mark.parametrize("name", ["b1", "b128", "b128reg", "b512"])
+def test_apr_step_golden(dev, golden_steps, name):
+    g = golden_steps
+    P, Q, b = [g["apr_%s_%s" % (name, k)] for k in "PQb"]
+    u, i, j = [g["apr_%s_%s" % (name, k)] for k in "uij"]
+    new, acc, dl, loss = run_apr(dev, P, Q, b, u, i, j, 0.05, float(g["apr_%s_reg" % name]), 1.0, 0.05)
+    tu = np.unique(u); ti = np.unique(np.concatenate([i, j]))
+    np.testing.assert_allclose(dl[0][tu], g["apr_%s_dP" % name][tu], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(dl[1][ti], g["apr_%s_dQ" % name][ti], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(dl[2][ti], g["apr_%s_db" % name][ti], rtol=1e-4, atol=1e-7)
+    for arr, k in zip(new + acc, ("P1", "Q1", "b1", "aP1", "aQ1", "ab1")):
+        np.testing.assert_allclose(arr, g["apr_%s_%s" % (name, k)], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(loss, g["apr_%s_loss" % name], rtol=1e-5)
+
+
+@pytest.mark.parametrize("U,I,d,B,reg", [(400, 300, 64, 5000, 0.0), (50, 40, 20, 3000, 0.02), (800, 500, 128, 2000, 0.0)])
+def test_apr_step_vs_oracle(dev, oracle, U, I, d, B, reg):
+    rng = np.random.default_rng(B)
+    P = rng.uniform(-0.3, 0.3, (U, d)).astype(np.float32)
+    Q = rng.uniform(-0.3, 0.3, (I, d)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, I).astype(np.float32)
+    u, i, j = [rng.integers(0, n, B).astype(np.int32) for n in (U, I, I)]
+    Po, Qo, bo = P.copy(), Q.copy(), b.copy()
+    aP, aQ, ab = [np.full_like(x, 0.1) for x in (P, Q, b)]
+    losses = oracle.apr_step(Po, Qo, bo, aP, aQ, ab, u, i, j, 0.05, reg, 1.0, 0.05)
+    new, acc, dl, loss = run_apr(dev, P, Q, b, u, i, j, 0.05, reg, 1.0, 0.05)
+    for got, ref, old in zip(new, (Po, Qo, bo), (P, Q, b)):
+        scale = max(np.abs(ref - old).max(), 1e-3)
+        assert np.abs(got - ref).max() <= 5e-5 * scale + 2e-7 * np.abs(ref).max()
+    for got, ref in zip(acc, (aP, aQ, ab)):
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(loss, losses, rtol=1e-5)
+
+
+def test_dns_select_golden_and_random(dev, oracle, golden_sampler):
+    g = golden_sampler
+    P, Q, b = g["dns_P"], g["dns_Q"], g["dns_b"]
+    users, pool = g["dns_users"], g["dns_pool"]
+    got = dev.dns_select(dev.array(P), dev.array(Q), dev.array(b), dev.array(users, np.int32), dev.array(pool, np.int32)).numpy()
+    ref, margin = oracle.dns_select(P, Q, b, users, pool)
+    ok = margin > 1e-5
+    assert ok.mean() > 0.9
+    assert np.array_equal(got[ok], g["dns_pick"][ok]) and np.array_equal(got[ok], ref[ok])
+    # every pick is one of that positive's candidates
+    assert all(got[t] in pool[t] for t in range(len(got)))
+    rng = np.random.default_rng(1)
+    for (U, I, d, n, Cn) in [(1000, 5000, 128, 4000, 32), (300, 700, 64, 1000, 15), (100, 50, 20, 500, 7)]:
+        P = rng.uniform(-0.5, 0.5, (U, d)).astype(np.float32)
+        Q = rng.uniform(-0.5, 0.5, (I, d)).astype(np.float32)
+        b = rng.uniform(-0.1, 0.1, I).astype(np.float32)
+        users = rng.integers(0, U, n).astype(np.int32)
+        cand = rng.integers(0, I, (n, Cn)).astype(np.int32)
+        cand[::7, 3] = cand[::7, 1]       # duplicated candidates: equal scores, the first one must win
+        got = dev.dns_select(dev.array(P), dev.array(Q), dev.array(b), dev.array(users), dev.array(cand)).numpy()
+        ref, margin = oracle.dns_select(P, Q, b, users, cand)
+        ok = margin > 1e-5
+        assert ok.mean() > 0.95 and np.array_equal(got[ok], ref[ok])
+
+
+def test_predict(dev):
+    rng = np.random.default_rng(2)
+    U, I, d, n = 300, 200, 20, 1000
+    P = rng.normal(size=(U, d)).astype(np.float32); Q = rng.normal(size=(I, d)).astype(np.float32)
+    b = rng.normal(size=I).astype(np.float32)
+    u = rng.integers(0, U, n).astype(np.int32); i = rng.integers(0, I, n).astype(np.int32)
+    y = dev.predict(dev.array(P), dev.array(Q), dev.array(b), dev.array(u), dev.array(i)).numpy()
+    ref = (P[u].astype(np.float64) * Q[i]).sum(1) + b[i]
+    np.testing.assert_allclose(y, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_fill_uniform_is_counter_based(dev):
+    a = dev.uniform((1000, 64), -0.05, 0.05, 2018).numpy()
+    c = dev.uniform((64000,), -0.05, 0.05, 2018).numpy()
+    assert np.array_equal(a.ravel(), c)
+    assert a.min() >= -0.05 and a.max() < 0.05 and abs(a.mean()) < 1e-3 and abs(a.std() - 0.1 / np.sqrt(12)) < 1e-3

@@ -1,0 +1,87 @@
+"""ctypes binding of libtfrec_amd.so (the C ABI declared in include/tfrec_amd.h).
+
+There is no CPU fallback: if the library is missing or does not load, importing the
+product path fails with an ImportError that says how to build it.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtfrec_amd.so")
+
+OK, EINVAL, EHIP, ENOMEM, EINDEX, EUNSUP = 0, -1, -2, -3, -4, -5
+SCORE_F32, SCORE_BF16 = 0, 1
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_int = C.c_int
+_f = C.c_float
+
+# name -> (restype, argtypes); one entry per symbol declared in include/tfrec_amd.h
+SIGNATURES = {
+    "tfrec_last_error": (C.c_char_p, []),
+    "tfrec_abi_version": (_int, []),
+    "tfrec_ctx_create": (_int, [_int, _p, C.POINTER(_p)]),
+    "tfrec_ctx_destroy": (_int, [_p]),
+    "tfrec_ctx_set_stream": (_int, [_p, _p]),
+    "tfrec_ctx_stream": (_p, [_p]),
+    "tfrec_ctx_synchronize": (_int, [_p]),
+    "tfrec_ctx_error_flags": (_int, [_p, C.POINTER(C.c_uint32), _int]),
+    "tfrec_ctx_reserve": (_int, [_p, _i64, _int, _i64, _int]),
+    "tfrec_ctx_workspace_bytes": (_i64, [_p]),
+    "tfrec_dev_malloc": (_int, [_p, C.c_size_t, C.POINTER(_p)]),
+    "tfrec_dev_free": (_int, [_p, _p]),
+    "tfrec_memcpy_h2d": (_int, [_p, _p, _p, C.c_size_t]),
+    "tfrec_memcpy_d2h": (_int, [_p, _p, _p, C.c_size_t]),
+    "tfrec_memset_zero": (_int, [_p, _p, C.c_size_t]),
+    "tfrec_fill_uniform": (_int, [_p, _p, _i64, _f, _f, C.c_uint64]),
+    "tfrec_fill_const": (_int, [_p, _p, _i64, _f]),
+    "tfrec_mf_predict": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _i64, _p]),
+    "tfrec_bpr_sgd_step": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _i64, _f, _f, _p]),
+    "tfrec_apr_adagrad_step": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _i64,
+                                      _f, _f, _f, _f, _p]),
+    "tfrec_dns_select": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _i64, _int, _p]),
+    "tfrec_score_topk": (_int, [_p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _i64, _p, _p, _int, _int, _p, _p]),
+    "tfrec_topk_merge": (_int, [_p, _p, _p, _int, _i64, _int, _p, _p]),
+    "tfrec_topk_fill_masked": (_int, [_p, _p, _p, _i64, _int, _p, _p]),
+    "tfrec_topk_dense": (_int, [_p, _p, _i64, _i64, _int, _p, _p, _p, _p, _p]),
+    "tfrec_rank_metrics": (_int, [_p, _p, _p, _i64, _int, _p, _p, _int, _p, _p]),
+    "tfrec_rank_metrics_sums": (_int, [_p, _p, _p, _i64, _int, _p, _p, _p, _p]),
+    "tfrec_eval_fullrank": (_int, [_p, _p, _p, _p, _i64, _int, _p, _i64, _p, _p, _p, _p, _int, _int, _int, _p, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the shared library once and attaches the signatures."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `make -C tfrec_amd/csrc -j8` (hipcc, gfx950) or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`.  There is no CPU fallback." % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise ImportError("could not load %s: %s (a ROCm runtime is required)" % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here = header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class TfrecError(RuntimeError):
+    pass
+
+
+_EXC = {EINVAL: ValueError, ENOMEM: MemoryError, EINDEX: IndexError, EUNSUP: NotImplementedError, EHIP: TfrecError}
+
+
+def check(rc):
+    if rc != OK:
+        msg = load().tfrec_last_error().decode("utf-8", "replace")
+        raise _EXC.get(rc, TfrecError)("tfrec_amd: %s (code %d)" % (msg, rc))

@@ -1,0 +1,232 @@
+// Shared host/device helpers of libtfrec_amd (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/tfrec_amd.h"
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+void tfrec_set_error(const char *fmt, ...);
+
+#define TF_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            tfrec_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return TFREC_EHIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+#define TF_REQUIRE(cond, code, ...)         \
+    do {                                    \
+        if (!(cond)) {                      \
+            tfrec_set_error(__VA_ARGS__);   \
+            return (code);                  \
+        }                                   \
+    } while (0)
+
+#define TF_TRY(expr)              \
+    do {                          \
+        int _rc = (expr);         \
+        if (_rc != TFREC_OK) return _rc; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// context: a device, a stream, and one growable workspace carved by a bump allocator
+// ------------------------------------------------------------------------------------------
+struct tfrec_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    char *ws = nullptr;          // device workspace
+    size_t ws_bytes = 0;
+    size_t ws_used = 0;          // bump pointer, reset at the start of every entry point
+    uint32_t *d_flags = nullptr; // sticky device-side error flags (4 bytes, separate allocation)
+    void *h_pinned = nullptr;    // small pinned staging buffer for host outputs
+    size_t h_pinned_bytes = 0;
+    int pinned_tab_k = 0;        // k for which the pinned 1/log2 table is filled
+};
+
+// Makes ctx's device current for the calling thread.
+int tfrec_ctx_enter(tfrec_ctx *ctx);
+// Ensures the workspace holds at least `bytes` (may reallocate: previous carve-outs die).
+int tfrec_ws_require(tfrec_ctx *ctx, size_t bytes);
+// Carves `bytes` (256-byte aligned) out of the workspace; tfrec_ws_require must have covered it.
+void *tfrec_ws_take(tfrec_ctx *ctx, size_t bytes);
+int tfrec_pinned_require(tfrec_ctx *ctx, size_t bytes);
+
+static inline size_t tf_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// rocPRIM-backed stable LSD radix sort of (key,value) pairs (sort.hip)
+size_t tfrec_sort_temp_bytes(size_t n, int end_bit);
+int tfrec_sort_pairs(void *d_temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
+                     const uint32_t *vals_in, uint32_t *vals_out, size_t n, int end_bit, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+// Butterfly exchange inside an aligned group of up to 64 lanes.  ds_swizzle's bit-mask mode
+// covers XOR masks below 32 without an address register; mask 32 goes through ds_bpermute.
+template <int MASK>
+__device__ __forceinline__ float lane_xor(float v)
+{
+    if constexpr (MASK < 32) {
+        // pattern: and_mask=0x1f, or_mask=0, xor_mask=MASK  (bit 15 clear = bit-mask mode)
+        return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (MASK << 10) | 0x1f));
+    } else {
+        return __shfl_xor(v, MASK, 64);
+    }
+}
+
+// Sum over an aligned group of LPR lanes; every lane of the group gets the total.  The
+// combination order is fixed, so the result does not depend on scheduling.
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v)
+{
+    if constexpr (LPR > 1) v += lane_xor<1>(v);
+    if constexpr (LPR > 2) v += lane_xor<2>(v);
+    if constexpr (LPR > 4) v += lane_xor<4>(v);
+    if constexpr (LPR > 8) v += lane_xor<8>(v);
+    if constexpr (LPR > 16) v += lane_xor<16>(v);
+    if constexpr (LPR > 32) v += lane_xor<32>(v);
+    return v;
+}
+
+// Read lane `src` (0..LPR-1, relative to the group) of every aligned LPR-lane group.
+template <int LPR>
+__device__ __forceinline__ uint32_t group_bcast(uint32_t v, int src)
+{
+    return (uint32_t)__shfl((int)v, src, LPR);
+}
+template <int LPR>
+__device__ __forceinline__ float group_bcastf(float v, int src)
+{
+    return __shfl(v, src, LPR);
+}
+
+// A row chunk: VEC floats (4 -> one 16-byte access per lane, 1 -> scalar fallback).
+template <int VEC>
+struct Chunk;
+template <>
+struct Chunk<4> {
+    float4 v;
+    __device__ __forceinline__ static Chunk zero() { return {make_float4(0.f, 0.f, 0.f, 0.f)}; }
+    __device__ __forceinline__ static Chunk load(const float *row, int c) { return {reinterpret_cast<const float4 *>(row)[c]}; }
+    __device__ __forceinline__ void store(float *row, int c) const { reinterpret_cast<float4 *>(row)[c] = v; }
+    __device__ __forceinline__ float dot(const Chunk &o) const { return v.x * o.v.x + v.y * o.v.y + v.z * o.v.z + v.w * o.v.w; }
+    __device__ __forceinline__ Chunk operator-(const Chunk &o) const { return {make_float4(v.x - o.v.x, v.y - o.v.y, v.z - o.v.z, v.w - o.v.w)}; }
+    __device__ __forceinline__ Chunk operator+(const Chunk &o) const { return {make_float4(v.x + o.v.x, v.y + o.v.y, v.z + o.v.z, v.w + o.v.w)}; }
+    __device__ __forceinline__ Chunk operator*(const Chunk &o) const { return {make_float4(v.x * o.v.x, v.y * o.v.y, v.z * o.v.z, v.w * o.v.w)}; }
+    __device__ __forceinline__ Chunk scaled(float s) const { return {make_float4(v.x * s, v.y * s, v.z * s, v.w * s)}; }
+    // this += s * o
+    __device__ __forceinline__ void fma(float s, const Chunk &o)
+    {
+        v.x = fmaf(s, o.v.x, v.x); v.y = fmaf(s, o.v.y, v.y); v.z = fmaf(s, o.v.z, v.z); v.w = fmaf(s, o.v.w, v.w);
+    }
+    template <class F>
+    __device__ __forceinline__ Chunk map2(const Chunk &o, F f) const { return {make_float4(f(v.x, o.v.x), f(v.y, o.v.y), f(v.z, o.v.z), f(v.w, o.v.w))}; }
+};
+template <>
+struct Chunk<1> {
+    float v;
+    __device__ __forceinline__ static Chunk zero() { return {0.f}; }
+    __device__ __forceinline__ static Chunk load(const float *row, int c) { return {row[c]}; }
+    __device__ __forceinline__ void store(float *row, int c) const { row[c] = v; }
+    __device__ __forceinline__ float dot(const Chunk &o) const { return v * o.v; }
+    __device__ __forceinline__ Chunk operator-(const Chunk &o) const { return {v - o.v}; }
+    __device__ __forceinline__ Chunk operator+(const Chunk &o) const { return {v + o.v}; }
+    __device__ __forceinline__ Chunk operator*(const Chunk &o) const { return {v * o.v}; }
+    __device__ __forceinline__ Chunk scaled(float s) const { return {v * s}; }
+    __device__ __forceinline__ void fma(float s, const Chunk &o) { v = fmaf(s, o.v, v); }
+    template <class F>
+    __device__ __forceinline__ Chunk map2(const Chunk &o, F f) const { return {f(v, o.v)}; }
+};
+
+// A whole row spread over an LPR-lane group: lane l holds chunks l, l+LPR, ... (NCH of them).
+// `nchunk` = chunks per row (d / VEC); lanes/chunks beyond it hold zeros and never touch memory.
+template <int LPR, int NCH, int VEC>
+struct Row {
+    Chunk<VEC> c[NCH];
+    __device__ __forceinline__ static Row zero()
+    {
+        Row r;
+#pragma unroll
+        for (int g = 0; g < NCH; ++g) r.c[g] = Chunk<VEC>::zero();
+        return r;
+    }
+    __device__ __forceinline__ static Row load(const float *row, int gl, int nchunk)
+    {
+        Row r;
+#pragma unroll
+        for (int g = 0; g < NCH; ++g) {
+            const int ci = gl + g * LPR;
+            r.c[g] = ci < nchunk ? Chunk<VEC>::load(row, ci) : Chunk<VEC>::zero();
+        }
+        return r;
+    }
+    __device__ __forceinline__ void store(float *row, int gl, int nchunk) const
+    {
+#pragma unroll
+        for (int g = 0; g < NCH; ++g) {
+            const int ci = gl + g * LPR;
+            if (ci < nchunk) c[g].store(row, ci);
+        }
+    }
+    // per-lane partial of <this, o>; finish with group_sum<LPR>
+    __device__ __forceinline__ float dot_partial(const Row &o) const
+    {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < NCH; ++g) s += c[g].dot(o.c[g]);
+        return s;
+    }
+    __device__ __forceinline__ Row operator-(const Row &o) const
+    {
+        Row r;
+#pragma unroll
+        for (int g = 0; g < NCH; ++g) r.c[g] = c[g] - o.c[g];
+        return r;
+    }
+    __device__ __forceinline__ Row operator+(const Row &o) const
+    {
+        Row r;
+#pragma unroll
+        for (int g = 0; g < NCH; ++g) r.c[g] = c[g] + o.c[g];
+        return r;
+    }
+    __device__ __forceinline__ void fma(float s, const Row &o)
+    {
+#pragma unroll
+        for (int g = 0; g < NCH; ++g) c[g].fma(s, o.c[g]);
+    }
+    template <class F>
+    __device__ __forceinline__ Row map2(const Row &o, F f) const
+    {
+        Row r;
+#pragma unroll
+        for (int g = 0; g < NCH; ++g) r.c[g] = c[g].map2(o.c[g], f);
+        return r;
+    }
+};
+
+// numerically stable pieces of the pairwise losses (float32)
+__device__ __forceinline__ float sigmoid_neg(float z)   // sigma(-z)
+{
+    const float e = __expf(-fabsf(z));
+    return z >= 0.f ? e / (1.f + e) : 1.f / (1.f + e);
+}
+__device__ __forceinline__ float softplus_neg(float z)  // log(1 + exp(-z))
+{
+    return fmaxf(-z, 0.f) + log1pf(__expf(-fabsf(z)));
+}
+
+#endif  // __HIPCC__

@@ -1,0 +1,845 @@
+// Full-rank evaluation: scoring of every (user, item) pair on the matrix cores with a running
+// top-k per user, top-k over dense rows, top-k merge, and the ranking metrics.
+//
+// score_topk_kernel never materialises the [users, items] score matrix that the reference
+// builds on the host (model/BPR.py:76-80) and masks in place
+// (evaluator/backend/cpp/evaluate.py:25-27).  A workgroup of four waves owns 128 users
+// (32 per wave, their factors resident in registers as the MFMA "B" operand) and streams
+// item tiles through LDS as the "A" operand:
+//     D[item][user] = bias[item] + sum_f Q[item][f] * P[user][f]
+//   * TFREC_SCORE_F32: v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain over f ascending that
+//     starts at the bias;
+//   * TFREC_SCORE_BF16: v_mfma_f32_32x32x16_bf16 on operands rounded to bfloat16.
+// In the accumulator layout a lane holds 16 items of ONE user, so one running threshold per
+// lane (the user's current k-th best score) filters the tile: a score above it is appended to
+// that user's candidate list.  When a list may overflow, the owning wave compacts it: drops
+// the user's train items (binary search in the sorted CSR row), bitonic-sorts the rest in LDS
+// under the total order (score descending, item id ascending) and keeps the best k, which
+// also tightens the threshold.  The reference's order among equal scores is whatever
+// std::partial_sort_copy leaves (evaluator/backend/cpp/tools.h:17); this order is the
+// documented replacement and makes item-sharded results merge exactly.
+#include "common.hpp"
+
+#include <cmath>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ------------------------------------------------------------------------------------------
+// keys: (score, id) packed so that a larger 64-bit key means "ranks earlier"
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f32_orderable(float x)
+{
+    const uint32_t u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float orderable_f32(uint32_t o)
+{
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+__device__ __forceinline__ uint64_t make_key(float score, int32_t id)
+{
+    return ((uint64_t)f32_orderable(score) << 32) | (uint32_t)(~(uint32_t)id);
+}
+__device__ __forceinline__ float key_score(uint64_t k) { return orderable_f32((uint32_t)(k >> 32)); }
+__device__ __forceinline__ int32_t key_id(uint64_t k) { return (int32_t)(~(uint32_t)k); }
+
+__device__ __forceinline__ bool csr_row_contains(const int32_t *__restrict__ idx, int64_t lo, int64_t hi, int32_t id)
+{
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const int32_t v = idx[mid];
+        if (v == id) return true;
+        if (v < id) lo = mid + 1; else hi = mid;
+    }
+    return false;
+}
+
+// Wave-wide bitonic sort of CAP 64-bit keys in LDS, descending.  All 64 lanes must call it.
+template <int CAP>
+__device__ __forceinline__ void wave_sort_desc(volatile uint64_t *buf, int lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int k2 = 2; k2 <= CAP; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int t = lane; t < CAP / 2; t += 64) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int p = i | j;
+                const uint64_t a = buf[i], b = buf[p];
+                const bool desc = (i & k2) == 0;
+                if ((a < b) == desc) { buf[i] = b; buf[p] = a; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// Compacts one candidate list.  list[0..cnt) holds keys; entries [0,ver) are known not to be
+// masked.  Drops masked ids, sorts, keeps the best k.  Returns the new count; *tau_out gets the
+// k-th best score (or -inf while fewer than k are held).  Wave-uniform arguments.
+template <int CAP>
+__device__ __forceinline__ int wave_compact(uint64_t *__restrict__ list, int cnt, int ver, int k,
+                                            const int32_t *__restrict__ mask_idx, int64_t mlo, int64_t mhi,
+                                            volatile uint64_t *sortbuf, int lane, float *tau_out)
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // this wave's own appends are visible
+    int kept = 0;
+#pragma unroll
+    for (int e = lane; e < CAP; e += 64) {
+        uint64_t key = 0;
+        if (e < cnt) {
+            key = list[e];
+            if (e >= ver && mask_idx && csr_row_contains(mask_idx, mlo, mhi, key_id(key))) key = 0;
+        }
+        sortbuf[e] = key;
+        kept += __popcll(__ballot(key != 0));
+    }
+    wave_sort_desc<CAP>(sortbuf, lane);
+    const int newc = kept < k ? kept : k;
+    for (int e = lane; e < newc; e += 64) list[e] = sortbuf[e];
+    *tau_out = newc >= k ? key_score(sortbuf[k - 1]) : -INFINITY;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    return newc;
+}
+
+// ------------------------------------------------------------------------------------------
+// item table preparation: padded float32 copy or bfloat16 copy of rows [item_lo, item_hi)
+// ------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ __launch_bounds__(256) void prep_items_kernel(const float *__restrict__ Q, int64_t item_lo, int64_t n_items, int d, int D,
+                                                         void *__restrict__ out)
+{
+    const int64_t total = n_items * D;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / D;
+        const int f = (int)(e - r * D);
+        const float v = f < d ? Q[(item_lo + r) * d + f] : 0.f;
+        if constexpr (BF16) reinterpret_cast<__bf16 *>(out)[e] = (__bf16)v;
+        else reinterpret_cast<float *>(out)[e] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fused scoring + top-k
+// ------------------------------------------------------------------------------------------
+struct ScoreArgs {
+    const float *P;            // [U, d]
+    const void *Qt;            // prepared item rows [n_items, D] (float or bf16), row 0 = item_lo
+    const float *b;            // [I] (global ids)
+    int d;
+    int64_t item_lo, n_items;  // shard
+    int64_t split_items;       // items per grid.y slice (multiple of the tile)
+    const int32_t *users;      // [n] evaluated users
+    int64_t n;
+    const int64_t *train_indptr;
+    const int32_t *train_indices;
+    int k;
+    uint64_t *lists;           // [gridDim.y, n, CAP]
+    int32_t *out_ids;          // [gridDim.y, n, k]
+    float *out_scores;         // [gridDim.y, n, k]
+};
+
+template <int D, bool BF16, int CAP>
+struct ScoreGeom {
+    static constexpr int ESZ = BF16 ? 2 : 4;
+    static constexpr int TI = (D * ESZ >= 512) ? 64 : 128;   // items per step
+    static constexpr int ROWB = D * ESZ + 16;                // padded LDS row (bank spread)
+    static constexpr int CPR = D * ESZ / 16;                 // 16-byte chunks per row
+    static constexpr int NLD = TI * CPR / 256;               // chunks per thread per tile
+    static constexpr int QBYTES = TI * ROWB;
+    static constexpr int LDS_BYTES = 2 * QBYTES + 2 * TI * 4 + 4 * CAP * 8 + 3 * 4 * 32 * 4;
+};
+
+template <int D, bool BF16, int CAP>
+__global__ __launch_bounds__(256) void score_topk_kernel(ScoreArgs a)
+{
+    using G = ScoreGeom<D, BF16, CAP>;
+    constexpr int TI = G::TI, ROWB = G::ROWB, CPR = G::CPR, NLD = G::NLD, ESZ = G::ESZ;
+    extern __shared__ __align__(16) char lds[];
+    char *qbuf = lds;                                                   // [2][TI*ROWB]
+    float *bias = reinterpret_cast<float *>(lds + 2 * G::QBYTES);        // [2][TI]
+    uint64_t *sortbuf = reinterpret_cast<uint64_t *>(bias + 2 * TI);     // [4][CAP]
+    int *cnt = reinterpret_cast<int *>(sortbuf + 4 * CAP);               // [4][32]
+    int *ver = cnt + 4 * 32;                                             // [4][32]
+    float *tau = reinterpret_cast<float *>(ver + 4 * 32);                // [4][32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int uj = lane & 31, h = lane >> 5;
+    const int64_t ur = (int64_t)blockIdx.x * 128 + wave * 32 + uj;       // evaluated-user ordinal
+    const bool uvalid = ur < a.n;
+    const int64_t urc = uvalid ? ur : a.n - 1;
+    const int32_t user = a.users[urc];
+    uint64_t *mylist = a.lists + ((size_t)blockIdx.y * a.n + urc) * CAP;
+    const int64_t it0 = (int64_t)blockIdx.y * a.split_items;             // first item (shard-relative)
+    const int64_t it1 = it0 + a.split_items < a.n_items ? it0 + a.split_items : a.n_items;
+
+    if (lane < 32) { cnt[wave * 32 + uj] = 0; ver[wave * 32 + uj] = 0; tau[wave * 32 + uj] = uvalid ? -INFINITY : INFINITY; }
+
+    // user factors -> B-operand fragments, resident for the whole scan
+    const float *prow = a.P + (size_t)user * a.d;
+    float pf[BF16 ? 1 : D / 2];
+    bf16x8 pb[BF16 ? D / 16 : 1];
+    if constexpr (BF16) {
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks) {
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int f = 16 * ks + 8 * h + j;
+                v[j] = (__bf16)(f < a.d ? prow[f] : 0.f);
+            }
+            pb[ks] = v;
+        }
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < D / 2; ++kk) {
+            const int f = 2 * kk + h;
+            pf[kk] = f < a.d ? prow[f] : 0.f;
+        }
+    }
+
+    // staging: thread -> NLD 16-byte chunks of the tile
+    uint4 stg[NLD];
+    float bstg = 0.f;
+    auto load_tile = [&](int64_t item_base) {
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) {
+            const int c = tid + 256 * m;
+            const int row = c / CPR, col = c % CPR;
+            const int64_t it = item_base + row;
+            stg[m] = it < it1 ? reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.Qt) + (size_t)it * D * ESZ)[col]
+                              : make_uint4(0, 0, 0, 0);
+        }
+        if (tid < TI) {
+            const int64_t it = item_base + tid;
+            bstg = it < it1 ? a.b[a.item_lo + it] : -INFINITY;    // -inf keeps padded items out of every list
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) {
+            const int c = tid + 256 * m;
+            const int row = c / CPR, col = c % CPR;
+            *reinterpret_cast<uint4 *>(qbuf + buf * G::QBYTES + row * ROWB + col * 16) = stg[m];
+        }
+        if (tid < TI) bias[buf * TI + tid] = bstg;
+    };
+
+    const int64_t mlo = a.train_indptr ? a.train_indptr[user] : 0;
+    const int64_t mhi = a.train_indptr ? a.train_indptr[user + 1] : 0;
+    volatile uint64_t *mysort = sortbuf + wave * CAP;
+
+    load_tile(it0);
+    store_tile(0);
+    __syncthreads();
+    const int64_t n_steps = (it1 - it0 + TI - 1) / TI;
+    for (int64_t step = 0; step < n_steps; ++step) {
+        const int buf = (int)(step & 1);
+        if (step + 1 < n_steps) load_tile(it0 + (step + 1) * TI);
+        const char *qb = qbuf + buf * G::QBYTES;
+        const float *bb = bias + buf * TI;
+#pragma unroll 1
+        for (int sb = 0; sb < TI / 32; ++sb) {
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *reinterpret_cast<const float4 *>(bb + sb * 32 + 8 * g + 4 * h);
+                acc[4 * g + 0] = bv.x; acc[4 * g + 1] = bv.y; acc[4 * g + 2] = bv.z; acc[4 * g + 3] = bv.w;
+            }
+            const char *arow = qb + (sb * 32 + uj) * ROWB;
+            if constexpr (BF16) {
+#pragma unroll
+                for (int ks = 0; ks < D / 16; ++ks) {
+                    const bf16x8 av = *reinterpret_cast<const bf16x8 *>(arow + (16 * ks + 8 * h) * 2);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pb[ks], acc, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < D / 4; ++c) {
+                    const float4 av = *reinterpret_cast<const float4 *>(arow + c * 16);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? av.y : av.x, pf[2 * c], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? av.w : av.z, pf[2 * c + 1], acc, 0, 0, 0);
+                }
+            }
+            // epilogue: filter the lane's 16 items against its user's threshold
+            const float th = tau[wave * 32 + uj];
+            float mx = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+            if (mx > th) {
+                const int32_t id0 = (int32_t)(a.item_lo + it0 + step * TI + sb * 32 + 4 * h);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (acc[r] > th) {
+                        const int pos = atomicAdd(&cnt[wave * 32 + uj], 1);
+                        mylist[pos] = make_key(acc[r], id0 + (r & 3) + 8 * (r >> 2));
+                    }
+                }
+            }
+            // a list that could overflow during the next 32 items is compacted now
+            uint64_t need = __ballot(lane < 32 && cnt[wave * 32 + uj] > CAP - 32);
+            while (need) {
+                const int src = __builtin_ctzll(need);
+                need &= need - 1;
+                const int64_t sur = (int64_t)blockIdx.x * 128 + wave * 32 + src;
+                uint64_t *sl = a.lists + ((size_t)blockIdx.y * a.n + sur) * CAP;
+                const int64_t slo = __shfl(mlo, src, 64), shi = __shfl(mhi, src, 64);
+                float nt;
+                const int nc = wave_compact<CAP>(sl, cnt[wave * 32 + src], ver[wave * 32 + src], a.k, a.train_indices, slo, shi,
+                                                 mysort, lane, &nt);
+                if (lane == 0) { cnt[wave * 32 + src] = nc; ver[wave * 32 + src] = nc; tau[wave * 32 + src] = nt; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+        }
+        if (step + 1 < n_steps) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // final compaction and output: the wave's 32 users one after the other
+    for (int src = 0; src < 32; ++src) {
+        const int64_t sur = (int64_t)blockIdx.x * 128 + wave * 32 + src;
+        if (sur >= a.n) break;     // wave-uniform
+        uint64_t *sl = a.lists + ((size_t)blockIdx.y * a.n + sur) * CAP;
+        const int64_t slo = __shfl(mlo, src, 64), shi = __shfl(mhi, src, 64);
+        float nt;
+        const int nc = wave_compact<CAP>(sl, cnt[wave * 32 + src], ver[wave * 32 + src], a.k, a.train_indices, slo, shi, mysort,
+                                         lane, &nt);
+        int32_t *oi = a.out_ids + ((size_t)blockIdx.y * a.n + sur) * a.k;
+        float *os = a.out_scores + ((size_t)blockIdx.y * a.n + sur) * a.k;
+        for (int e = lane; e < a.k; e += 64) {
+            const uint64_t key = e < nc ? mysort[e] : 0;
+            oi[e] = e < nc ? key_id(key) : -1;
+            os[e] = e < nc ? key_score(key) : -INFINITY;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// top-k of dense rows: one wave per row (replaces c_top_k_array_index, tools.h:22-30)
+// ------------------------------------------------------------------------------------------
+template <int CAP>
+__global__ __launch_bounds__(256) void topk_dense_kernel(const float *__restrict__ R, int64_t rows, int64_t cols, int k,
+                                                         const int32_t *__restrict__ mask_rows, const int64_t *__restrict__ mptr,
+                                                         const int32_t *__restrict__ midx, uint64_t *__restrict__ lists,
+                                                         int32_t *__restrict__ out_ids, float *__restrict__ out_scores)
+{
+    __shared__ uint64_t sortbuf[4][CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const float *src = R + (size_t)row * cols;
+    uint64_t *list = lists + (size_t)row * CAP;
+    int64_t mlo = 0, mhi = 0;
+    if (mptr) {
+        const int64_t mr = mask_rows ? mask_rows[row] : row;
+        mlo = mptr[mr];
+        mhi = mptr[mr + 1];
+    }
+    int cnt = 0, ver = 0;
+    float tau = -INFINITY;
+    for (int64_t c0 = 0; c0 < cols; c0 += 256) {
+        if (cnt > CAP - 256) {
+            cnt = wave_compact<CAP>(list, cnt, ver, k, midx, mlo, mhi, sortbuf[wave], lane, &tau);
+            ver = cnt;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t c = c0 + q * 64 + lane;
+            const float v = c < cols ? src[c] : -INFINITY;
+            const bool pass = v > tau;
+            const uint64_t m = __ballot(pass);
+            if (pass) list[cnt + __popcll(m & ((1ull << lane) - 1))] = make_key(v, (int32_t)c);
+            cnt += __popcll(m);
+        }
+    }
+    cnt = wave_compact<CAP>(list, cnt, ver, k, midx, mlo, mhi, sortbuf[wave], lane, &tau);
+    for (int e = lane; e < k; e += 64) {
+        const uint64_t key = e < cnt ? sortbuf[wave][e] : 0;
+        out_ids[(size_t)row * k + e] = e < cnt ? key_id(key) : -1;
+        if (out_scores) out_scores[(size_t)row * k + e] = e < cnt ? key_score(key) : -INFINITY;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// merge of G top-k lists per user (item-sharded evaluation, or item splits of one GPU)
+// ------------------------------------------------------------------------------------------
+template <int CAP>
+__global__ __launch_bounds__(256) void topk_merge_kernel(const int32_t *__restrict__ ids, const float *__restrict__ scores, int G,
+                                                         int64_t n, int k, int32_t *__restrict__ out_ids,
+                                                         float *__restrict__ out_scores)
+{
+    __shared__ uint64_t sortbuf[4][CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t u = (int64_t)blockIdx.x * 4 + wave;
+    if (u >= n) return;
+    volatile uint64_t *sb = sortbuf[wave];
+    const int total = G * k;
+    int kept = 0;
+    for (int e = lane; e < CAP; e += 64) {
+        uint64_t key = 0;
+        if (e < total) {
+            const int g = e / k, r = e - g * k;
+            const int32_t id = ids[((size_t)g * n + u) * k + r];
+            if (id >= 0) key = make_key(scores[((size_t)g * n + u) * k + r], id);
+        }
+        sb[e] = key;
+        kept += __popcll(__ballot(key != 0));
+    }
+    wave_sort_desc<CAP>(sb, lane);
+    const int nc = kept < k ? kept : k;
+    for (int e = lane; e < k; e += 64) {
+        const uint64_t key = e < nc ? sb[e] : 0;
+        out_ids[(size_t)u * k + e] = e < nc ? key_id(key) : -1;
+        out_scores[(size_t)u * k + e] = e < nc ? key_score(key) : -INFINITY;
+    }
+}
+
+// ids still -1 are filled with the user's train items in ascending order (the reference's
+// ranking runs into its -inf masked entries when fewer than k items are rankable)
+__global__ __launch_bounds__(256) void fill_masked_kernel(int32_t *__restrict__ ids, const int32_t *__restrict__ users, int64_t n,
+                                                          int k, const int64_t *__restrict__ tptr, const int32_t *__restrict__ tidx)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    int32_t *row = ids + (size_t)r * k;
+    int c = 0;
+    while (c < k && row[c] >= 0) ++c;
+    const int32_t u = users[r];
+    int64_t t = tptr[u];
+    const int64_t te = tptr[u + 1];
+    for (; c < k && t < te; ++c, ++t) row[c] = tidx[t];
+}
+
+// ------------------------------------------------------------------------------------------
+// metrics: one thread per user, arithmetic exactly as evaluator/backend/cpp/metrics.h:11-100
+// (double inner arithmetic, float running sums and stores)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void metrics_user_kernel(const int32_t *__restrict__ ids, const int32_t *__restrict__ users,
+                                                           int64_t n, int k, const int64_t *__restrict__ tptr,
+                                                           const int32_t *__restrict__ tidx, const double *__restrict__ inv_log2,
+                                                           float *__restrict__ per_user)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const int32_t u = users[r];
+    const int64_t lo = tptr[u], hi = tptr[u + 1];
+    const int n_truth = (int)(hi - lo);
+    const int32_t *rank = ids + (size_t)r * k;
+    float *pre = per_user + (size_t)r * 5 * k, *rec = pre + k, *apv = pre + 2 * k, *nd = pre + 3 * k, *mr = pre + 4 * k;
+    int hits = 0, first = -1;
+    float sum_pre = 0.f, dcg = 0.f, idcg = 0.f;
+    for (int i = 0; i < k; ++i) {
+        const int32_t id = rank[i];
+        const bool hit = id >= 0 && csr_row_contains(tidx, lo, hi, id);
+        hits += hit;
+        const float p = (float)(1.0 * hits / (i + 1));
+        pre[i] = p;
+        rec[i] = (float)(1.0 * hits / n_truth);
+        if (hit) sum_pre += p;
+        apv[i] = (float)(1.0 * (double)sum_pre / (n_truth < i + 1 ? n_truth : i + 1));
+        if (hit) dcg = (float)((double)dcg + inv_log2[i]);
+        idcg = (float)((double)idcg + inv_log2[i]);
+        nd[i] = dcg / idcg;
+        if (hit && first < 0) first = i;
+        mr[i] = first >= 0 ? (float)(1.0 / (first + 1)) : 0.f;
+    }
+}
+
+// column sums of per_user [n, C] in a fixed order: grid (column chunk, user chunk)
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ per_user, int64_t n, int C, int64_t users_per_chunk,
+                                                     double *__restrict__ partial)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t u0 = (int64_t)blockIdx.y * users_per_chunk;
+    const int64_t u1 = u0 + users_per_chunk < n ? u0 + users_per_chunk : n;
+    double s = 0.0;
+    for (int64_t u = u0; u < u1; ++u) s += (double)per_user[(size_t)u * C + c];
+    partial[(size_t)blockIdx.y * C + c] = s;
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const double *__restrict__ partial, int n_chunks, int C, double *__restrict__ sums,
+                                                           int accumulate)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = accumulate ? sums[c] : 0.0;
+    for (int j = 0; j < n_chunks; ++j) s += partial[(size_t)j * C + c];
+    sums[c] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static int cap_for_k(int k) { return k <= 112 ? 256 : (k <= 240 ? 512 : 0); }
+
+template <int D, bool BF16, int CAP>
+static int launch_score(tfrec_ctx *ctx, const ScoreArgs &a, int user_blocks, int splits)
+{
+    using G = ScoreGeom<D, BF16, CAP>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        TF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&score_topk_kernel<D, BF16, CAP>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+        attr_set = true;
+    }
+    score_topk_kernel<D, BF16, CAP><<<dim3(user_blocks, splits), 256, G::LDS_BYTES, ctx->stream>>>(a);
+    TF_HIP(hipGetLastError());
+    return TFREC_OK;
+}
+
+template <int CAP>
+static int launch_score_cap(tfrec_ctx *ctx, const ScoreArgs &a, int D, int mode, int user_blocks, int splits)
+{
+    if (mode == TFREC_SCORE_BF16) {
+        switch (D) {
+            case 32: return launch_score<32, true, CAP>(ctx, a, user_blocks, splits);
+            case 64: return launch_score<64, true, CAP>(ctx, a, user_blocks, splits);
+            case 128: return launch_score<128, true, CAP>(ctx, a, user_blocks, splits);
+            case 256: return launch_score<256, true, CAP>(ctx, a, user_blocks, splits);
+        }
+    } else {
+        switch (D) {
+            case 32: return launch_score<32, false, CAP>(ctx, a, user_blocks, splits);
+            case 64: return launch_score<64, false, CAP>(ctx, a, user_blocks, splits);
+            case 128: return launch_score<128, false, CAP>(ctx, a, user_blocks, splits);
+        }
+    }
+    tfrec_set_error("internal: no scoring kernel for D=%d", D);
+    return TFREC_EUNSUP;
+}
+
+static int merge_lists(tfrec_ctx *ctx, const int32_t *ids, const float *scores, int G, int64_t n, int k, int32_t *out_ids,
+                       float *out_scores)
+{
+    const int blocks = (int)((n + 3) / 4);
+    const int total = G * k;
+    if (total <= 256) topk_merge_kernel<256><<<blocks, 256, 0, ctx->stream>>>(ids, scores, G, n, k, out_ids, out_scores);
+    else if (total <= 512) topk_merge_kernel<512><<<blocks, 256, 0, ctx->stream>>>(ids, scores, G, n, k, out_ids, out_scores);
+    else if (total <= 1024) topk_merge_kernel<1024><<<blocks, 256, 0, ctx->stream>>>(ids, scores, G, n, k, out_ids, out_scores);
+    else if (total <= 2048) topk_merge_kernel<2048><<<blocks, 256, 0, ctx->stream>>>(ids, scores, G, n, k, out_ids, out_scores);
+    else { tfrec_set_error("merge of %d lists of %d exceeds 2048 entries", G, k); return TFREC_EUNSUP; }
+    TF_HIP(hipGetLastError());
+    return TFREC_OK;
+}
+
+extern "C" int tfrec_topk_merge(tfrec_ctx *ctx, const int32_t *d_ids, const float *d_scores, int G, int64_t n, int k,
+                                int32_t *d_out_ids, float *d_out_scores)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_REQUIRE(G >= 1 && n >= 0 && k >= 1, TFREC_EINVAL, "bad merge shape G=%d n=%lld k=%d", G, (long long)n, k);
+    if (n == 0) return TFREC_OK;
+    TF_REQUIRE(d_ids && d_scores && d_out_ids && d_out_scores, TFREC_EINVAL, "null pointer");
+    return merge_lists(ctx, d_ids, d_scores, G, n, k, d_out_ids, d_out_scores);
+}
+
+static int pad_dim(int d, int mode)
+{
+    if (d <= 32) return 32;
+    if (d <= 64) return 64;
+    if (d <= 128) return 128;
+    if (d <= 256 && mode == TFREC_SCORE_BF16) return 256;
+    return 0;
+}
+
+struct ScorePlan {
+    int CAP, D, TI, splits;
+    bool bf16, direct;
+    int64_t n_items, split_items, chunk;
+    size_t q_bytes, list_bytes, part_bytes, total;
+};
+
+static int plan_score(const float *d_Q, int d, int64_t item_lo, int64_t item_hi, int64_t n, int k, int score_mode, ScorePlan *p)
+{
+    p->CAP = cap_for_k(k);
+    TF_REQUIRE(p->CAP != 0, TFREC_EUNSUP, "top-k above 240 is not supported (k=%d)", k);
+    p->D = pad_dim(d, score_mode);
+    TF_REQUIRE(p->D != 0, TFREC_EUNSUP, "factor size d=%d is not supported for this score mode", d);
+    p->n_items = item_hi - item_lo;
+    p->bf16 = score_mode == TFREC_SCORE_BF16;
+    p->direct = !p->bf16 && d == p->D && (((uintptr_t)d_Q) & 15u) == 0;
+    p->TI = (p->D * (p->bf16 ? 2 : 4) >= 512) ? 64 : 128;
+    p->chunk = 1 << 20;          // users per launch: bounds the candidate-list workspace
+    const int64_t user_blocks_all = (n + 127) / 128;
+    int splits = 1;
+    if (user_blocks_all < 512 && p->n_items > 0) {
+        // few users: also split the item range over workgroups, then merge the partial lists
+        const int64_t want = (512 + user_blocks_all - 1) / user_blocks_all;
+        const int64_t maxs = (p->n_items + 4095) / 4096;
+        splits = (int)(want < maxs ? want : maxs);
+        if (splits < 1) splits = 1;
+        if ((int64_t)splits * k > 2048) splits = 2048 / k;
+    }
+    p->split_items = p->n_items > 0 ? ((p->n_items + splits - 1) / splits + p->TI - 1) / p->TI * p->TI : p->TI;
+    p->splits = p->n_items > 0 ? (int)((p->n_items + p->split_items - 1) / p->split_items) : 1;
+    const int64_t nc = n < p->chunk ? n : p->chunk;
+    p->q_bytes = p->direct ? 0 : tf_align((size_t)p->n_items * p->D * (p->bf16 ? 2 : 4));
+    p->list_bytes = tf_align(sizeof(uint64_t) * (size_t)p->splits * nc * p->CAP);
+    p->part_bytes = p->splits > 1 ? tf_align((size_t)p->splits * nc * k * 4) : 0;
+    p->total = p->q_bytes + p->list_bytes + 2 * p->part_bytes + 4096;
+    return TFREC_OK;
+}
+
+static int score_topk_impl(tfrec_ctx *ctx, const float *d_P, const float *d_Q, const float *d_b, int64_t I, int d,
+                           int64_t item_lo, int64_t item_hi, const int32_t *d_eval_users, int64_t n,
+                           const int64_t *d_train_indptr, const int32_t *d_train_indices, int k, int score_mode,
+                           int32_t *d_out_ids, float *d_out_scores)
+{
+    TF_REQUIRE(d_P && d_Q && d_b, TFREC_EINVAL, "null table pointer");
+    TF_REQUIRE(0 <= item_lo && item_lo <= item_hi && item_hi <= I, TFREC_EINVAL, "bad item range [%lld,%lld) of %lld",
+               (long long)item_lo, (long long)item_hi, (long long)I);
+    TF_REQUIRE(I < (1ll << 31), TFREC_EUNSUP, "item ids must fit in int32");
+    TF_REQUIRE(n >= 0 && k >= 1, TFREC_EINVAL, "bad n or k");
+    TF_REQUIRE(score_mode == TFREC_SCORE_F32 || score_mode == TFREC_SCORE_BF16, TFREC_EINVAL, "unknown score mode %d", score_mode);
+    TF_REQUIRE((d_train_indptr == nullptr) == (d_train_indices == nullptr), TFREC_EINVAL, "train CSR needs both arrays");
+    if (n == 0) return TFREC_OK;
+    TF_REQUIRE(d_eval_users && d_out_ids && d_out_scores, TFREC_EINVAL, "null pointer");
+    ScorePlan pl;
+    TF_TRY(plan_score(d_Q, d, item_lo, item_hi, n, k, score_mode, &pl));
+    const int CAP = pl.CAP, D = pl.D, splits = pl.splits;
+    const bool bf16 = pl.bf16, direct = pl.direct;
+    const int64_t n_items = pl.n_items, split_items = pl.split_items, chunk_max = pl.chunk;
+    if (n_items == 0) {
+        // an empty shard: every slot is "no candidate" (id -1 = 0xffffffff, score -inf = 0xff800000)
+        TF_HIP(hipMemsetAsync(d_out_ids, 0xff, sizeof(int32_t) * n * k, ctx->stream));
+        TF_HIP(hipMemsetD32Async((hipDeviceptr_t)d_out_scores, (int)0xff800000u, (size_t)n * k, ctx->stream));
+        return TFREC_OK;
+    }
+    TF_TRY(tfrec_ws_require(ctx, ctx->ws_used + pl.total));
+    void *qt = direct ? nullptr : tfrec_ws_take(ctx, pl.q_bytes);
+    uint64_t *lists = (uint64_t *)tfrec_ws_take(ctx, pl.list_bytes);
+    int32_t *part_ids = splits > 1 ? (int32_t *)tfrec_ws_take(ctx, pl.part_bytes) : nullptr;
+    float *part_sc = splits > 1 ? (float *)tfrec_ws_take(ctx, pl.part_bytes) : nullptr;
+    TF_REQUIRE(lists != nullptr, TFREC_ENOMEM, "internal: workspace carve failed");
+
+    if (!direct) {
+        const int64_t total = n_items * D;
+        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        if (bf16) prep_items_kernel<true><<<blocks, 256, 0, ctx->stream>>>(d_Q, item_lo, n_items, d, D, qt);
+        else prep_items_kernel<false><<<blocks, 256, 0, ctx->stream>>>(d_Q, item_lo, n_items, d, D, qt);
+        TF_HIP(hipGetLastError());
+    }
+
+    for (int64_t u0 = 0; u0 < n; u0 += chunk_max) {
+        const int64_t nn = n - u0 < chunk_max ? n - u0 : chunk_max;
+        ScoreArgs a{};
+        a.P = d_P;
+        a.Qt = direct ? (const void *)(d_Q + (size_t)item_lo * d) : qt;
+        a.b = d_b;
+        a.d = d;
+        a.item_lo = item_lo;
+        a.n_items = n_items;
+        a.split_items = split_items;
+        a.users = d_eval_users + u0;
+        a.n = nn;
+        a.train_indptr = d_train_indptr;
+        a.train_indices = d_train_indices;
+        a.k = k;
+        a.lists = lists;
+        a.out_ids = splits > 1 ? part_ids : d_out_ids + (size_t)u0 * k;
+        a.out_scores = splits > 1 ? part_sc : d_out_scores + (size_t)u0 * k;
+        const int user_blocks = (int)((nn + 127) / 128);
+        if (CAP == 256) TF_TRY(launch_score_cap<256>(ctx, a, D, score_mode, user_blocks, splits));
+        else TF_TRY(launch_score_cap<512>(ctx, a, D, score_mode, user_blocks, splits));
+        if (splits > 1) TF_TRY(merge_lists(ctx, part_ids, part_sc, splits, nn, k, d_out_ids + (size_t)u0 * k, d_out_scores + (size_t)u0 * k));
+    }
+    return TFREC_OK;
+}
+
+extern "C" int tfrec_score_topk(tfrec_ctx *ctx, const float *d_P, const float *d_Q, const float *d_b, int64_t I, int d,
+                                int64_t item_lo, int64_t item_hi, const int32_t *d_eval_users, int64_t n,
+                                const int64_t *d_train_indptr, const int32_t *d_train_indices, int k, int score_mode,
+                                int32_t *d_out_ids, float *d_out_scores)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    return score_topk_impl(ctx, d_P, d_Q, d_b, I, d, item_lo, item_hi, d_eval_users, n, d_train_indptr, d_train_indices, k,
+                           score_mode, d_out_ids, d_out_scores);
+}
+
+extern "C" int tfrec_topk_fill_masked(tfrec_ctx *ctx, int32_t *d_ids, const int32_t *d_eval_users, int64_t n, int k,
+                                      const int64_t *d_train_indptr, const int32_t *d_train_indices)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    if (n == 0 || !d_train_indptr) return TFREC_OK;
+    TF_REQUIRE(d_ids && d_eval_users && d_train_indices, TFREC_EINVAL, "null pointer");
+    fill_masked_kernel<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(d_ids, d_eval_users, n, k, d_train_indptr, d_train_indices);
+    TF_HIP(hipGetLastError());
+    return TFREC_OK;
+}
+
+extern "C" int tfrec_topk_dense(tfrec_ctx *ctx, const float *d_ratings, int64_t rows, int64_t cols, int k,
+                                const int32_t *d_mask_rows, const int64_t *d_mask_indptr, const int32_t *d_mask_indices,
+                                int32_t *d_out_ids, float *d_out_scores)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_REQUIRE(rows >= 0 && cols >= 1 && k >= 1, TFREC_EINVAL, "bad shape rows=%lld cols=%lld k=%d", (long long)rows, (long long)cols, k);
+    TF_REQUIRE(cols < (1ll << 31), TFREC_EUNSUP, "column ids must fit in int32");
+    TF_REQUIRE(k <= 240, TFREC_EUNSUP, "top-k above 240 is not supported (k=%d)", k);
+    TF_REQUIRE((d_mask_indptr == nullptr) == (d_mask_indices == nullptr), TFREC_EINVAL, "mask CSR needs both arrays");
+    if (rows == 0) return TFREC_OK;
+    TF_REQUIRE(d_ratings && d_out_ids, TFREC_EINVAL, "null pointer");
+    constexpr int CAP = 512;
+    const size_t list_bytes = tf_align(sizeof(uint64_t) * (size_t)rows * CAP);
+    TF_TRY(tfrec_ws_require(ctx, ctx->ws_used + list_bytes + 4096));
+    uint64_t *lists = (uint64_t *)tfrec_ws_take(ctx, list_bytes);
+    TF_REQUIRE(lists != nullptr, TFREC_ENOMEM, "internal: workspace carve failed");
+    topk_dense_kernel<CAP><<<(int)((rows + 3) / 4), 256, 0, ctx->stream>>>(d_ratings, rows, cols, k, d_mask_rows, d_mask_indptr,
+                                                                          d_mask_indices, lists, d_out_ids, d_out_scores);
+    TF_HIP(hipGetLastError());
+    return TFREC_OK;
+}
+
+// per-user curves + column sums; leaves [5k] double sums in d_sums.  Scratch is carved above
+// whatever the caller already holds in the workspace.
+static size_t metrics_need(int64_t n, int k, bool have_rows)
+{
+    const int C = 5 * k;
+    const int64_t chunk = have_rows ? n : (n < (1 << 18) ? n : (1 << 18));
+    const int64_t max_chunks = (chunk + 1023) / 1024;
+    return (have_rows ? 0 : tf_align(sizeof(float) * (size_t)chunk * C)) + tf_align(sizeof(double) * (size_t)max_chunks * C) +
+           tf_align(sizeof(double) * k) + 4096;
+}
+
+static int metrics_sums(tfrec_ctx *ctx, const int32_t *d_ids, const int32_t *d_users, int64_t n, int k, const int64_t *tptr,
+                        const int32_t *tidx, float *d_per_user, double *d_sums)
+{
+    const int C = 5 * k;
+    const int64_t chunk = d_per_user ? n : (n < (1 << 18) ? n : (1 << 18));   // users per pass when the rows are scratch
+    const int64_t upc = 1024;                                                  // users per column-sum block
+    const int64_t max_chunks = (chunk + upc - 1) / upc;
+    TF_TRY(tfrec_ws_require(ctx, ctx->ws_used + metrics_need(n, k, d_per_user != nullptr)));
+    float *rows = d_per_user ? d_per_user : (float *)tfrec_ws_take(ctx, sizeof(float) * (size_t)chunk * C);
+    double *partial = (double *)tfrec_ws_take(ctx, sizeof(double) * (size_t)max_chunks * C);
+    double *tab = (double *)tfrec_ws_take(ctx, sizeof(double) * k);
+    TF_REQUIRE(rows && partial && tab, TFREC_ENOMEM, "internal: workspace carve failed");
+    // 1/log2(i+2) from the host's libm, so the device adds exactly the doubles metrics.h:69-71 adds
+    TF_TRY(tfrec_pinned_require(ctx, sizeof(double) * (k + C)));
+    double *h_tab = (double *)ctx->h_pinned;
+    if (ctx->pinned_tab_k != k) {
+        TF_HIP(hipStreamSynchronize(ctx->stream));     // an earlier upload may still be reading the table
+        for (int i = 0; i < k; ++i) h_tab[i] = 1.0 / std::log2((double)(i + 2));
+        ctx->pinned_tab_k = k;
+    }
+    TF_HIP(hipMemcpyAsync(tab, h_tab, sizeof(double) * k, hipMemcpyHostToDevice, ctx->stream));
+    for (int64_t u0 = 0; u0 < n; u0 += chunk) {
+        const int64_t nn = n - u0 < chunk ? n - u0 : chunk;
+        float *rp = d_per_user ? d_per_user + (size_t)u0 * C : rows;
+        metrics_user_kernel<<<(int)((nn + 255) / 256), 256, 0, ctx->stream>>>(d_ids + (size_t)u0 * k, d_users + u0, nn, k, tptr, tidx,
+                                                                              tab, rp);
+        TF_HIP(hipGetLastError());
+        const int nchunks = (int)((nn + upc - 1) / upc);
+        colsum_kernel<<<dim3((C + 255) / 256, nchunks), 256, 0, ctx->stream>>>(rp, nn, C, upc, partial);
+        TF_HIP(hipGetLastError());
+        colsum_final_kernel<<<(C + 255) / 256, 256, 0, ctx->stream>>>(partial, nchunks, C, d_sums, u0 > 0);
+        TF_HIP(hipGetLastError());
+    }
+    return TFREC_OK;
+}
+
+extern "C" int tfrec_rank_metrics_sums(tfrec_ctx *ctx, const int32_t *d_ids, const int32_t *d_eval_users, int64_t n, int k,
+                                       const int64_t *d_test_indptr, const int32_t *d_test_indices, float *d_per_user,
+                                       double *d_sums)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_REQUIRE(n >= 0 && k >= 1, TFREC_EINVAL, "bad n or k");
+    TF_REQUIRE(d_sums != nullptr, TFREC_EINVAL, "null output");
+    if (n == 0) { TF_HIP(hipMemsetAsync(d_sums, 0, sizeof(double) * 5 * k, ctx->stream)); return TFREC_OK; }
+    TF_REQUIRE(d_ids && d_eval_users && d_test_indptr && d_test_indices, TFREC_EINVAL, "null pointer");
+    return metrics_sums(ctx, d_ids, d_eval_users, n, k, d_test_indptr, d_test_indices, d_per_user, d_sums);
+}
+
+static size_t metrics_host_need(int64_t n, int k, int mean_mode, bool have_rows)
+{
+    const int C = 5 * k;
+    size_t s = tf_align(sizeof(double) * C) + 4096;
+    if (mean_mode == 1 && !have_rows) s += tf_align(sizeof(float) * (size_t)n * C);
+    return s + metrics_need(n, k, have_rows || mean_mode == 1);
+}
+
+static int metrics_to_host(tfrec_ctx *ctx, const int32_t *d_ids, const int32_t *d_users, int64_t n, int k, const int64_t *tptr,
+                           const int32_t *tidx, int mean_mode, float *d_per_user, float *h_mean)
+{
+    const int C = 5 * k;
+    TF_TRY(tfrec_ws_require(ctx, ctx->ws_used + metrics_host_need(n, k, mean_mode, d_per_user != nullptr)));
+    double *d_sums = (double *)tfrec_ws_take(ctx, sizeof(double) * C);
+    float *rows = d_per_user;
+    if (mean_mode == 1 && !rows) rows = (float *)tfrec_ws_take(ctx, sizeof(float) * (size_t)n * C);
+    TF_REQUIRE(d_sums && (mean_mode == 0 || rows), TFREC_ENOMEM, "internal: workspace carve failed");
+    TF_TRY(metrics_sums(ctx, d_ids, d_users, n, k, tptr, tidx, rows, d_sums));
+    if (mean_mode == 1) {
+        // per-user rows to the host, summed sequentially in float32 in user order (evaluate.h:40-92)
+        std::vector<float> host((size_t)n * C);
+        TF_HIP(hipMemcpyAsync(host.data(), rows, sizeof(float) * (size_t)n * C, hipMemcpyDeviceToHost, ctx->stream));
+        TF_HIP(hipStreamSynchronize(ctx->stream));
+        for (int c = 0; c < C; ++c) h_mean[c] = 0.f;
+        for (int64_t u = 0; u < n; ++u)
+            for (int c = 0; c < C; ++c) h_mean[c] += host[(size_t)u * C + c];
+        for (int c = 0; c < C; ++c) h_mean[c] /= (float)n;
+        return TFREC_OK;
+    }
+    double *h = (double *)ctx->h_pinned + k;
+    TF_HIP(hipMemcpyAsync(h, d_sums, sizeof(double) * C, hipMemcpyDeviceToHost, ctx->stream));
+    TF_HIP(hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < C; ++c) h_mean[c] = (float)(h[c] / (double)n);
+    return TFREC_OK;
+}
+
+extern "C" int tfrec_rank_metrics(tfrec_ctx *ctx, const int32_t *d_ids, const int32_t *d_eval_users, int64_t n, int k,
+                                  const int64_t *d_test_indptr, const int32_t *d_test_indices, int mean_mode,
+                                  float *d_per_user, float *h_mean)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_REQUIRE(n >= 1 && k >= 1, TFREC_EINVAL, "bad n or k");
+    TF_REQUIRE(d_ids && d_eval_users && d_test_indptr && d_test_indices && h_mean, TFREC_EINVAL, "null pointer");
+    TF_REQUIRE(mean_mode == 0 || mean_mode == 1, TFREC_EINVAL, "unknown mean mode %d", mean_mode);
+    return metrics_to_host(ctx, d_ids, d_eval_users, n, k, d_test_indptr, d_test_indices, mean_mode, d_per_user, h_mean);
+}
+
+// evaluation scratch that depends only on the number of users and k (candidate lists, id and
+// score buffers, metric rows); the prepared item table comes on top for bf16 / padded scoring
+size_t tfrec_eval_scratch_bytes(int64_t n, int k)
+{
+    const int CAP = cap_for_k(k);
+    if (!CAP) return 0;
+    const int64_t nc = n < (1 << 20) ? n : (1 << 20);
+    return 2 * tf_align(4 * (size_t)n * k) + tf_align(sizeof(uint64_t) * (size_t)nc * CAP) + metrics_host_need(n, k, 0, false) + 8192;
+}
+
+// workspace bytes one full evaluation needs
+size_t tfrec_eval_need_bytes(const float *d_Q, int64_t I, int d, int64_t n, int k, int score_mode, int mean_mode)
+{
+    ScorePlan pl;
+    if (plan_score(d_Q, d, 0, I, n, k, score_mode, &pl) != TFREC_OK) return 0;
+    return 2 * tf_align(4 * (size_t)n * k) + pl.total + metrics_host_need(n, k, mean_mode, false) + 4096;
+}
+
+extern "C" int tfrec_eval_fullrank(tfrec_ctx *ctx, const float *d_P, const float *d_Q, const float *d_b, int64_t I, int d,
+                                   const int32_t *d_eval_users, int64_t n, const int64_t *d_train_indptr,
+                                   const int32_t *d_train_indices, const int64_t *d_test_indptr, const int32_t *d_test_indices,
+                                   int k, int score_mode, int mean_mode, int32_t *d_out_ids, float *h_mean)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_REQUIRE(n >= 1 && k >= 1 && h_mean, TFREC_EINVAL, "bad n, k or output");
+    TF_REQUIRE(d_test_indptr && d_test_indices && d_eval_users, TFREC_EINVAL, "null test CSR or user list");
+    TF_REQUIRE(mean_mode == 0 || mean_mode == 1, TFREC_EINVAL, "unknown mean mode %d", mean_mode);
+    // size the workspace once for all stages: growing it later would move the buffers carved here
+    const size_t need = tfrec_eval_need_bytes(d_Q, I, d, n, k, score_mode, mean_mode);
+    TF_REQUIRE(need != 0, TFREC_EUNSUP, "unsupported k=%d or d=%d for this score mode", k, d);
+    TF_TRY(tfrec_ws_require(ctx, need));
+    int32_t *ids = d_out_ids ? d_out_ids : (int32_t *)tfrec_ws_take(ctx, sizeof(int32_t) * (size_t)n * k);
+    float *scores = (float *)tfrec_ws_take(ctx, sizeof(float) * (size_t)n * k);
+    TF_REQUIRE(ids && scores, TFREC_ENOMEM, "internal: workspace carve failed");
+    const size_t floor = ctx->ws_used;
+    TF_TRY(score_topk_impl(ctx, d_P, d_Q, d_b, I, d, 0, I, d_eval_users, n, d_train_indptr, d_train_indices, k, score_mode, ids,
+                           scores));
+    if (d_train_indptr) {
+        fill_masked_kernel<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(ids, d_eval_users, n, k, d_train_indptr, d_train_indices);
+        TF_HIP(hipGetLastError());
+    }
+    ctx->ws_used = floor;    // the scoring scratch is dead (stream order), the metrics reuse it
+    return metrics_to_host(ctx, ids, d_eval_users, n, k, d_test_indptr, d_test_indices, mean_mode, nullptr, h_mean);
+}

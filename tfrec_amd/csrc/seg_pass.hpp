@@ -1,0 +1,304 @@
+// Atomic-free segmented reduction over occurrences sorted by destination row.
+//
+// Input: `keys` (destination row ids, ascending) and `vals` (occurrence ids) for positions
+// [base, base+n).  A *segment* is a maximal run of equal keys: all contributions to one row.
+// The positions are cut into fixed tiles of CH occurrences; one aligned group of LPR lanes
+// (LPR*VEC*NCH >= d floats: the group holds one whole row, 16 bytes per lane) walks one tile
+// in order and keeps the running sum of the current segment in registers.
+//
+//   * a segment that lies entirely inside a tile is finished on the spot (Pol::apply);
+//   * a segment cut by a tile boundary leaves per-tile partial sums (at most one "lead"
+//     partial for the segment entering the tile and one "tail" partial for the segment
+//     leaving it).  seg_fixup_kernel then adds, for every segment, its tail partial and the
+//     lead partials of the following tiles in tile order and applies the result.
+//
+// Every sum is formed in an order fixed by the sorted input alone, so results are bitwise
+// reproducible; no atomics touch the tables.  Tiles have equal work whatever the skew of
+// the keys, and a row hit by thousands of occurrences (hot item) is spread over many tiles;
+// its long chain of partials is summed cooperatively by a whole workgroup.
+//
+// A policy `Pol` supplies the arithmetic:
+//   struct Pol { enum { LPR, NCH, VEC }; using RowT = Row<LPR,NCH,VEC>;
+//     struct Occ;  struct Seg;  struct Loss;
+//     uint2 aux(uint32_t key, uint32_t val)                 -> two extra indices staged per entry
+//     Occ  load_occ(uint4 entry, int gl)                    -> gathers of one occurrence
+//     Seg  load_seg(uint32_t key, int gl)                   -> the destination row(s)
+//     void compute(Seg&, const Occ&, uint4 entry, Acc<RowT>&, Loss&, int gl)
+//     void apply(uint32_t key, const Seg*, const Acc<RowT>&, int gl)   (Seg==nullptr: load it)
+//   };
+#pragma once
+#include "common.hpp"
+
+template <class RowT>
+struct Acc {
+    RowT v;
+    float s0, s1;
+    int cnt;
+    __device__ __forceinline__ void clear() { v = RowT::zero(); s0 = 0.f; s1 = 0.f; cnt = 0; }
+    __device__ __forceinline__ void add(const Acc &o) { v = v + o.v; s0 += o.s0; s1 += o.s1; cnt += o.cnt; }
+};
+
+template <int LPR>
+struct TileGeom {
+    static constexpr int CH = LPR > 32 ? LPR : 32;   // occurrences per tile
+    static constexpr int EPL = CH / LPR;             // entries staged per lane
+    static constexpr int GPB = 256 / LPR;            // groups (= tiles) per 256-thread workgroup
+};
+
+enum : uint32_t { LEAD_NONE = 0, LEAD_END = 1, LEAD_THROUGH = 2, TAIL_BIT = 4 };
+static constexpr uint32_t NOKEY = 0xffffffffu;
+static constexpr int FIX_SHORT = 8;    // chains up to this many tiles are walked by one group
+
+// Partial records: rows [2*nTiles][ROWF] floats, scalars [2*nTiles] float4 {s0, s1, cnt, -}.
+template <class RowT, int LPR, int NCH, int VEC>
+__device__ __forceinline__ void part_store(float *rows, float4 *sc, int64_t slot, const Acc<RowT> &a, int gl)
+{
+    constexpr int ROWF = LPR * NCH * VEC;
+    a.v.store(rows + slot * ROWF, gl, LPR * NCH);
+    if (gl == 0) sc[slot] = make_float4(a.s0, a.s1, __int_as_float(a.cnt), 0.f);
+}
+template <class RowT, int LPR, int NCH, int VEC>
+__device__ __forceinline__ Acc<RowT> part_load(const float *rows, const float4 *sc, int64_t slot, int gl)
+{
+    constexpr int ROWF = LPR * NCH * VEC;
+    Acc<RowT> a;
+    a.v = RowT::load(rows + slot * ROWF, gl, LPR * NCH);
+    const float4 s = sc[slot];
+    a.s0 = s.x; a.s1 = s.y; a.cnt = __float_as_int(s.z);
+    return a;
+}
+
+// Sum of a workgroup's per-thread (rank, reg) loss terms, written as two doubles per block.
+template <class Loss>
+__device__ __forceinline__ void block_loss_store(const Loss &loss, double *loss_part)
+{
+    __shared__ double red[4][Loss::N];
+    double v[Loss::N];
+#pragma unroll
+    for (int i = 0; i < Loss::N; ++i) {
+        v[i] = (double)loss.t[i];
+        for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_down(v[i], off, 64);
+    }
+    if ((threadIdx.x & 63) == 0)
+        for (int i = 0; i < Loss::N; ++i) red[threadIdx.x >> 6][i] = v[i];
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int i = 0; i < Loss::N; ++i)
+            loss_part[(size_t)blockIdx.x * Loss::N + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+
+template <int N_>
+struct LossAcc {
+    static constexpr int N = N_;
+    float t[N_ > 0 ? N_ : 1];
+    __device__ __forceinline__ void clear()
+    {
+        for (int i = 0; i < (N_ > 0 ? N_ : 1); ++i) t[i] = 0.f;
+    }
+};
+
+template <class Pol>
+__global__ __launch_bounds__(256) void seg_tile_kernel(Pol pol, const uint32_t *__restrict__ keys,
+                                                       const uint32_t *__restrict__ vals, int64_t base, int64_t n,
+                                                       float *__restrict__ part_rows, float4 *__restrict__ part_sc,
+                                                       uint32_t *__restrict__ tile_flags, double *__restrict__ loss_part)
+{
+    constexpr int LPR = Pol::LPR, NCH = Pol::NCH, VEC = Pol::VEC;
+    using RowT = typename Pol::RowT;
+    using G = TileGeom<LPR>;
+    constexpr int CH = G::CH, EPL = G::EPL, GPB = G::GPB;
+    __shared__ uint4 ent[GPB][CH];
+
+    const int gl = threadIdx.x % LPR;
+    const int g = threadIdx.x / LPR;
+    const int64_t w = (int64_t)blockIdx.x * GPB + g;
+    const int64_t a = w * CH;
+    const int cnt = a < n ? (int)((n - a) < CH ? (n - a) : CH) : 0;
+
+    // stage this tile's entries {key, val, aux0, aux1}: coalesced index reads, one dependent gather
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        const int e = s * LPR + gl;
+        if (e < cnt) {
+            const uint32_t k = keys[base + a + e], v = vals[base + a + e];
+            const uint2 ax = pol.aux(k, v);
+            ent[g][e] = make_uint4(k, v, ax.x, ax.y);
+        }
+    }
+    __syncthreads();
+
+    typename Pol::Loss loss;
+    loss.clear();
+    if (cnt > 0) {
+        const uint32_t key_prev = a > 0 ? keys[base + a - 1] : NOKEY;
+        const uint32_t key_next = a + cnt < n ? keys[base + a + cnt] : NOKEY;
+        uint32_t lead_kind = LEAD_NONE, tail = 0;
+
+        uint4 en = ent[g][0];
+        typename Pol::Occ nx = pol.load_occ(en, gl);
+        typename Pol::Seg nseg = pol.load_seg(en.x, gl);
+        typename Pol::Seg seg = nseg;
+        Acc<RowT> acc;
+        acc.clear();
+        bool lead_open = (en.x == key_prev);
+        uint32_t cur_key = en.x;
+
+        for (int e = 0; e < cnt; ++e) {
+            const typename Pol::Occ cur = nx;
+            if (en.x != cur_key) {
+                // the previous segment ended inside this tile
+                if (lead_open) {
+                    part_store<RowT, LPR, NCH, VEC>(part_rows, part_sc, 2 * w, acc, gl);
+                    lead_kind = LEAD_END;
+                } else {
+                    pol.apply(cur_key, &seg, acc, gl);
+                }
+                lead_open = false;
+                cur_key = en.x;
+                seg = nseg;
+                acc.clear();
+            }
+            const uint4 en_now = en;
+            if (e + 1 < cnt) {   // issue the next occurrence's gathers before working on this one
+                en = ent[g][e + 1];
+                nx = pol.load_occ(en, gl);
+                if (en.x != cur_key) nseg = pol.load_seg(en.x, gl);
+            }
+            pol.compute(seg, cur, en_now, acc, loss, gl);
+        }
+        // last segment of the tile
+        const bool continues = (key_next == cur_key);
+        if (lead_open) {
+            part_store<RowT, LPR, NCH, VEC>(part_rows, part_sc, 2 * w, acc, gl);
+            lead_kind = continues ? LEAD_THROUGH : LEAD_END;
+        } else if (continues) {
+            part_store<RowT, LPR, NCH, VEC>(part_rows, part_sc, 2 * w + 1, acc, gl);
+            tail = TAIL_BIT;
+        } else {
+            pol.apply(cur_key, &seg, acc, gl);
+        }
+        if (gl == 0) tile_flags[w] = lead_kind | tail;
+    }
+    if constexpr (Pol::Loss::N > 0) block_loss_store(loss, loss_part);
+}
+
+// Finishes the segments that were cut by tile boundaries.
+template <class Pol>
+__global__ __launch_bounds__(256) void seg_fixup_kernel(Pol pol, const uint32_t *__restrict__ keys, int64_t base, int64_t n,
+                                                        const float *__restrict__ part_rows, const float4 *__restrict__ part_sc,
+                                                        const uint32_t *__restrict__ tile_flags, int64_t n_tiles)
+{
+    constexpr int LPR = Pol::LPR, NCH = Pol::NCH, VEC = Pol::VEC;
+    using RowT = typename Pol::RowT;
+    using G = TileGeom<LPR>;
+    constexpr int CH = G::CH, GPB = G::GPB;
+    constexpr int ROWF = LPR * NCH * VEC;
+    __shared__ int64_t long_w[GPB];
+    __shared__ int long_n;
+    __shared__ int first_end;
+    __shared__ __align__(16) float red_rows[GPB][ROWF];
+    __shared__ float4 red_sc[GPB];
+
+    const int gl = threadIdx.x % LPR;
+    const int g = threadIdx.x / LPR;
+    const int64_t w = (int64_t)blockIdx.x * GPB + g;
+    if (threadIdx.x == 0) long_n = 0;
+    __syncthreads();
+
+    if (w < n_tiles && (tile_flags[w] & TAIL_BIT)) {
+        const int64_t last = ((w + 1) * CH < n ? (w + 1) * CH : n) - 1;
+        const uint32_t key = keys[base + last];
+        Acc<RowT> tot = part_load<RowT, LPR, NCH, VEC>(part_rows, part_sc, 2 * w + 1, gl);
+        bool done = false;
+        int64_t m = w + 1;
+        for (int step = 0; step < FIX_SHORT; ++step, ++m) {
+            if (m >= n_tiles) { done = true; break; }          // cannot happen: the last tile never continues
+            const uint32_t f = tile_flags[m] & 3u;
+            if (f == LEAD_NONE) { done = true; break; }        // defensive: nothing to add
+            tot.add(part_load<RowT, LPR, NCH, VEC>(part_rows, part_sc, 2 * m, gl));
+            if (f == LEAD_END) { done = true; break; }
+        }
+        if (done) {
+            pol.apply(key, nullptr, tot, gl);
+        } else if (gl == 0) {
+            long_w[atomicAdd(&long_n, 1)] = w;
+        }
+    }
+    __syncthreads();
+    const int n_long = long_n;
+    // long chains (a row with more than FIX_SHORT*CH occurrences): the whole workgroup sums one
+    for (int c = 0; c < n_long; ++c) {
+        // chains are taken in ascending tile order so the result does not depend on who registered first
+        int64_t wl = -1;
+        {
+            int64_t best = INT64_MAX;
+            for (int i = 0; i < n_long; ++i) {
+                const int64_t x = long_w[i];
+                int rank = 0;
+                for (int j = 0; j < n_long; ++j) rank += (long_w[j] < x);
+                if (rank == c) best = x;
+            }
+            wl = best;
+        }
+        // length of the chain: first following tile whose lead partial ends the segment
+        if (threadIdx.x == 0) first_end = INT32_MAX;
+        __syncthreads();
+        int L = 0;
+        for (int64_t r0 = 0;; r0 += 256) {
+            const int64_t idx = wl + 1 + r0 + threadIdx.x;
+            const bool end_here = idx >= n_tiles || (tile_flags[idx] & 3u) != LEAD_THROUGH;
+            if (end_here) atomicMin(&first_end, (int)(r0 + threadIdx.x));
+            __syncthreads();
+            const int fe = first_end;
+            __syncthreads();
+            if (fe != INT32_MAX) { L = fe + 1; break; }
+        }
+        if (wl + L >= n_tiles) L = (int)(n_tiles - 1 - wl);
+        // group gi sums a contiguous share of the lead partials wl+1 .. wl+L, in tile order
+        const int per = (L + GPB - 1) / GPB;
+        Acc<RowT> part;
+        part.clear();
+        {
+            const int lo = g * per, hi = (g + 1) * per < L ? (g + 1) * per : L;
+            for (int t = lo; t < hi; ++t)
+                part.add(part_load<RowT, LPR, NCH, VEC>(part_rows, part_sc, 2 * (wl + 1 + t), gl));
+        }
+        part.v.store(&red_rows[g][0], gl, LPR * NCH);
+        if (gl == 0) red_sc[g] = make_float4(part.s0, part.s1, __int_as_float(part.cnt), 0.f);
+        __syncthreads();
+        if (g == 0) {
+            const int64_t last = ((wl + 1) * CH < n ? (wl + 1) * CH : n) - 1;
+            const uint32_t key = keys[base + last];
+            Acc<RowT> tot = part_load<RowT, LPR, NCH, VEC>(part_rows, part_sc, 2 * wl + 1, gl);
+            for (int i = 0; i < GPB; ++i) {
+                Acc<RowT> pi;
+                pi.v = RowT::load(&red_rows[i][0], gl, LPR * NCH);
+                const float4 s = red_sc[i];
+                pi.s0 = s.x; pi.s1 = s.y; pi.cnt = __float_as_int(s.z);
+                tot.add(pi);
+            }
+            pol.apply(key, nullptr, tot, gl);
+        }
+        __syncthreads();
+    }
+}
+
+// Sums per-block loss partials [n_blocks][N] into out[N]; one workgroup, fixed order.
+template <int N>
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const double *__restrict__ part, int n_blocks, double *__restrict__ out)
+{
+    __shared__ double red[256][N];
+    double v[N];
+    for (int i = 0; i < N; ++i) v[i] = 0.0;
+    for (int b = threadIdx.x; b < n_blocks; b += 256)
+        for (int i = 0; i < N; ++i) v[i] += part[(size_t)b * N + i];
+    for (int i = 0; i < N; ++i) red[threadIdx.x][i] = v[i];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s)
+            for (int i = 0; i < N; ++i) red[threadIdx.x][i] += red[threadIdx.x + s][i];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        for (int i = 0; i < N; ++i) out[i] = red[0][i];
+}

@@ -1,0 +1,226 @@
+"""Device context: the Python face of the C ABI (include/tfrec_amd.h).
+
+It stands where the reference passes a ``tf.Session`` (run_model.py:14-16): models receive a
+``Device`` as their ``sess`` argument.  Buffers are either ``DevArray`` objects (memory owned by
+this module through tfrec_dev_malloc) or torch tensors on the same GPU (borrowed through
+``data_ptr()``); both are just a pointer, a shape and a dtype to the library.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+SCORE_F32 = _lib.SCORE_F32
+SCORE_BF16 = _lib.SCORE_BF16
+
+
+class DevArray:
+    """A typed device allocation (row-major)."""
+
+    def __init__(self, dev, shape, dtype):
+        self.dev = dev
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        _lib.check(dev.lib.tfrec_dev_malloc(dev.h, max(self.nbytes, 1), C.byref(p)))
+        self.ptr = p.value
+
+    def __len__(self):
+        return self.shape[0]
+
+    def numpy(self):
+        out = np.empty(self.shape, self.dtype)
+        _lib.check(self.dev.lib.tfrec_memcpy_d2h(self.dev.h, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def copy_from(self, host):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        if host.nbytes != self.nbytes:
+            raise ValueError("size mismatch: %d vs %d bytes" % (host.nbytes, self.nbytes))
+        _lib.check(self.dev.lib.tfrec_memcpy_h2d(self.dev.h, self.ptr, host.ctypes.data, self.nbytes))
+        return self
+
+    def free(self):
+        if self.ptr and self.dev.h:
+            self.dev.lib.tfrec_dev_free(self.dev.h, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _ptr(x):
+    """Device pointer of a DevArray, a torch tensor, an int, or None."""
+    if x is None:
+        return None
+    if isinstance(x, DevArray):
+        return x.ptr
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "data_ptr"):
+        if not x.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        return x.data_ptr()
+    raise TypeError("not a device buffer: %r" % type(x))
+
+
+def _shape(x):
+    return tuple(x.shape)
+
+
+class Device:
+    """One GPU, one stream, one workspace.  Not re-entrant."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self.lib.tfrec_ctx_create(int(device), stream, C.byref(h)))
+        self.h = h.value
+        self.device = int(device)
+
+    def close(self):
+        if self.h:
+            self.lib.tfrec_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- memory -----------------------------------------------------------------------------
+    def empty(self, shape, dtype=np.float32):
+        return DevArray(self, shape, dtype)
+
+    def array(self, host, dtype=None):
+        host = np.ascontiguousarray(host, dtype=dtype)
+        return DevArray(self, host.shape, host.dtype).copy_from(host)
+
+    def zeros(self, shape, dtype=np.float32):
+        a = DevArray(self, shape, dtype)
+        _lib.check(self.lib.tfrec_memset_zero(self.h, a.ptr, a.nbytes))
+        return a
+
+    def full(self, shape, value):
+        a = DevArray(self, shape, np.float32)
+        _lib.check(self.lib.tfrec_fill_const(self.h, a.ptr, a.nbytes // 4, float(value)))
+        return a
+
+    def uniform(self, shape, lo, hi, seed):
+        a = DevArray(self, shape, np.float32)
+        _lib.check(self.lib.tfrec_fill_uniform(self.h, a.ptr, a.nbytes // 4, float(lo), float(hi), int(seed)))
+        return a
+
+    def synchronize(self):
+        """Waits for the stream; raises IndexError if a batch held an out-of-range index."""
+        _lib.check(self.lib.tfrec_ctx_synchronize(self.h))
+
+    def reserve(self, max_batch=0, d=0, max_eval_users=0, k=0):
+        _lib.check(self.lib.tfrec_ctx_reserve(self.h, int(max_batch), int(d), int(max_eval_users), int(k)))
+
+    def workspace_bytes(self):
+        return int(self.lib.tfrec_ctx_workspace_bytes(self.h))
+
+    @property
+    def stream(self):
+        return self.lib.tfrec_ctx_stream(self.h)
+
+    # -- model math -------------------------------------------------------------------------
+    def predict(self, P, Q, b, users, items, out=None):
+        U, d = _shape(P)
+        I = _shape(Q)[0]
+        n = _shape(users)[0]
+        out = out if out is not None else self.empty(n, np.float32)
+        _lib.check(self.lib.tfrec_mf_predict(self.h, _ptr(P), _ptr(Q), _ptr(b), U, I, d, _ptr(users), _ptr(items), n, _ptr(out)))
+        return out
+
+    def bpr_sgd_step(self, P, Q, b, users, pos, neg, lr, reg, loss=None):
+        """One minibatch step (model/BPR.py:36-48 + :72).  ``loss``: optional device float64[2]."""
+        U, d = _shape(P)
+        I = _shape(Q)[0]
+        B = _shape(users)[0]
+        _lib.check(self.lib.tfrec_bpr_sgd_step(self.h, _ptr(P), _ptr(Q), _ptr(b), U, I, d, _ptr(users), _ptr(pos), _ptr(neg), B,
+                                               float(lr), float(reg), _ptr(loss)))
+
+    def apr_adagrad_step(self, P, Q, b, accP, accQ, accb, dP, dQ, db, users, pos, neg, lr, reg, reg_adv, eps, loss=None):
+        """Both session calls of model/APR.py:163-164.  ``loss``: optional device float64[3]."""
+        U, d = _shape(P)
+        I = _shape(Q)[0]
+        B = _shape(users)[0]
+        _lib.check(self.lib.tfrec_apr_adagrad_step(self.h, _ptr(P), _ptr(Q), _ptr(b), _ptr(accP), _ptr(accQ), _ptr(accb),
+                                                   _ptr(dP), _ptr(dQ), _ptr(db), U, I, d, _ptr(users), _ptr(pos), _ptr(neg), B,
+                                                   float(lr), float(reg), float(reg_adv), float(eps), _ptr(loss)))
+
+    def dns_select(self, P, Q, b, users, cand, out=None):
+        """cand: int32 [n_pos, C] -> best-scored candidate per positive (model/DNSBPR.py:74-79)."""
+        U, d = _shape(P)
+        I = _shape(Q)[0]
+        n, Cn = _shape(cand)
+        out = out if out is not None else self.empty(n, np.int32)
+        _lib.check(self.lib.tfrec_dns_select(self.h, _ptr(P), _ptr(Q), _ptr(b), U, I, d, _ptr(users), _ptr(cand), n, Cn, _ptr(out)))
+        return out
+
+    # -- evaluation -------------------------------------------------------------------------
+    def score_topk(self, P, Q, b, eval_users, k, train=None, mode=SCORE_F32, item_range=None, out_ids=None, out_scores=None):
+        """train: (indptr int64 dev, indices int32 dev) or None.  Returns (ids [n,k], scores [n,k])."""
+        d = _shape(P)[1]
+        I = _shape(Q)[0]
+        n = _shape(eval_users)[0]
+        lo, hi = item_range if item_range is not None else (0, I)
+        out_ids = out_ids if out_ids is not None else self.empty((n, k), np.int32)
+        out_scores = out_scores if out_scores is not None else self.empty((n, k), np.float32)
+        tp, ti = (train if train is not None else (None, None))
+        _lib.check(self.lib.tfrec_score_topk(self.h, _ptr(P), _ptr(Q), _ptr(b), I, d, lo, hi, _ptr(eval_users), n, _ptr(tp), _ptr(ti),
+                                             int(k), int(mode), _ptr(out_ids), _ptr(out_scores)))
+        return out_ids, out_scores
+
+    def topk_merge(self, ids, scores, G, n, k, out_ids=None, out_scores=None):
+        out_ids = out_ids if out_ids is not None else self.empty((n, k), np.int32)
+        out_scores = out_scores if out_scores is not None else self.empty((n, k), np.float32)
+        _lib.check(self.lib.tfrec_topk_merge(self.h, _ptr(ids), _ptr(scores), int(G), int(n), int(k), _ptr(out_ids), _ptr(out_scores)))
+        return out_ids, out_scores
+
+    def topk_fill_masked(self, ids, eval_users, k, train):
+        n = _shape(eval_users)[0]
+        _lib.check(self.lib.tfrec_topk_fill_masked(self.h, _ptr(ids), _ptr(eval_users), n, int(k), _ptr(train[0]), _ptr(train[1])))
+
+    def topk_dense(self, R, k, mask=None, mask_rows=None, out_ids=None, out_scores=None):
+        rows, cols = _shape(R)
+        out_ids = out_ids if out_ids is not None else self.empty((rows, k), np.int32)
+        out_scores = out_scores if out_scores is not None else self.empty((rows, k), np.float32)
+        mp, mi = (mask if mask is not None else (None, None))
+        _lib.check(self.lib.tfrec_topk_dense(self.h, _ptr(R), rows, cols, int(k), _ptr(mask_rows), _ptr(mp), _ptr(mi),
+                                             _ptr(out_ids), _ptr(out_scores)))
+        return out_ids, out_scores
+
+    def rank_metrics(self, ids, eval_users, k, test, mean_mode=0, per_user=None):
+        """test: (indptr, indices) device CSR.  Returns float32 [5,k]: Precision, Recall, MAP, NDCG, MRR."""
+        n = _shape(eval_users)[0]
+        out = np.empty((5, k), np.float32)
+        _lib.check(self.lib.tfrec_rank_metrics(self.h, _ptr(ids), _ptr(eval_users), n, int(k), _ptr(test[0]), _ptr(test[1]),
+                                               int(mean_mode), _ptr(per_user), out.ctypes.data))
+        return out
+
+    def rank_metrics_sums(self, ids, eval_users, k, test, sums=None, per_user=None):
+        n = _shape(eval_users)[0]
+        sums = sums if sums is not None else self.empty(5 * k, np.float64)
+        _lib.check(self.lib.tfrec_rank_metrics_sums(self.h, _ptr(ids), _ptr(eval_users), n, int(k), _ptr(test[0]), _ptr(test[1]),
+                                                    _ptr(per_user), _ptr(sums)))
+        return sums
+
+    def eval_fullrank(self, P, Q, b, eval_users, train, test, k, mode=SCORE_F32, mean_mode=0, out_ids=None):
+        d = _shape(P)[1]
+        I = _shape(Q)[0]
+        n = _shape(eval_users)[0]
+        out = np.empty((5, k), np.float32)
+        tp, ti = (train if train is not None else (None, None))
+        _lib.check(self.lib.tfrec_eval_fullrank(self.h, _ptr(P), _ptr(Q), _ptr(b), I, d, _ptr(eval_users), n, _ptr(tp), _ptr(ti),
+                                                _ptr(test[0]), _ptr(test[1]), int(k), int(mode), int(mean_mode), _ptr(out_ids),
+                                                out.ctypes.data))
+        return out
