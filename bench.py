@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Benchmark of the matrix-factorization ranking hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" is one BPR-MF minibatch step (gather, dot, pairwise loss forward/backward, duplicate
+reduction, SGD row updates) over one batch of synthetic triples that is already resident in
+HBM.  N=1 runs the single-GPU configuration the metric is quoted on (1M users x 200k items,
+d=64, fp32); N>1 (launched by torch.distributed.run, one rank per GPU) runs the row-sharded
+tables with an all-to-all exchange of item rows and gradients per step, weak scaling (the
+per-GPU batch is fixed).  Rank 0 prints ONE JSON line.
+
+Extra objects on that line: "roofline" (the step's kernels against the HBM roofline, timed
+with HIP events on the stream the library launches on), "cpu_baseline" (the CPU oracle timed
+on this host, rank 0, N=1 only) and "eval" (full-rank evaluation users/s, timed separately,
+outside the K training steps).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
+
+
+def zipf_items(n_items, size, gen, device, alpha=1.0):
+    """Items ~ Zipf(alpha) over a random permutation of the ids (hot rows exist)."""
+    w = 1.0 / torch.arange(1, n_items + 1, device=device, dtype=torch.float64) ** alpha
+    cdf = torch.cumsum(w, 0)
+    cdf = cdf / cdf[-1]
+    out = torch.empty(size, device=device, dtype=torch.int32)
+    perm = torch.randperm(n_items, device=device, generator=gen)
+    chunk = 1 << 24
+    for s in range(0, size, chunk):
+        n = min(chunk, size - s)
+        r = torch.rand(n, device=device, dtype=torch.float64, generator=gen)
+        out[s:s + n] = perm[torch.searchsorted(cdf, r).clamp_(max=n_items - 1)].to(torch.int32)
+    return out
+
+
+def cpu_baseline(U, I, d, B, lr, reg, budget_s=12.0):
+    """The CPU oracle (plain C, one thread) on the same table shapes and batch distribution."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    rng = np.random.default_rng(2018)
+    P = rng.uniform(-0.05, 0.05, (U, d)).astype(np.float32)
+    Q = rng.uniform(-0.05, 0.05, (I, d)).astype(np.float32)
+    b = np.zeros(I, np.float32)
+    w = 1.0 / np.arange(1, I + 1)
+    cdf = np.cumsum(w) / w.sum()
+    perm = rng.permutation(I)
+    ws = orc.Workspace(U, I, d)
+    done, t_used, steps = 0, 0.0, 0
+    while t_used < budget_s:
+        users = rng.integers(0, U, B).astype(np.int32)
+        pos = perm[np.searchsorted(cdf, rng.random(B)).clip(max=I - 1)].astype(np.int32)
+        neg = rng.integers(0, I, B).astype(np.int32)
+        t0 = time.perf_counter()
+        orc.bpr_step(P, Q, b, users, pos, neg, lr, reg, ws=ws)
+        t_used += time.perf_counter() - t0
+        done += B
+        steps += 1
+    return {"value": done / t_used, "unit": "triples/s", "cores": 1, "kind": "port",
+            "sample": "%d steps of %d triples on the same %dx%d d=%d tables (oracle/mf_oracle.c, scalar C, step math only)"
+                      % (steps, B, U, I, d)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1 << 20, help="triples per step per GPU")
+    ap.add_argument("--users", type=int, default=1_000_000)
+    ap.add_argument("--items", type=int, default=200_000)
+    ap.add_argument("--factors", type=int, default=64)
+    ap.add_argument("--interactions", type=int, default=100_000_000)
+    ap.add_argument("--eval-users", type=int, default=262_144)
+    ap.add_argument("--topk", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-eval", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    cuda = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=cuda)
+
+    from tfrec_amd.device import Device, SCORE_F32, SCORE_BF16
+    stream = torch.cuda.Stream(device=cuda)
+    lr, reg = 0.01, 0.05                                   # conf/BPR.ini
+    U, I, d, B = args.users, args.items, args.factors, args.batch
+    gen = torch.Generator(device=cuda)
+    gen.manual_seed(2018 + rank)
+    n_batches = max(1, min(args.interactions // (B * world), 16))    # distinct batches resident in HBM, cycled
+
+    with torch.cuda.stream(stream):
+        dev = Device(local_rank, stream=stream.cuda_stream)
+        if world == 1:
+            P = (torch.rand(U, d, device=cuda, generator=gen) - 0.5) * 0.1     # U(-0.05, 0.05)
+            Q = (torch.rand(I, d, device=cuda, generator=gen) - 0.5) * 0.1
+            b = torch.zeros(I, device=cuda)
+            users = torch.randint(0, U, (n_batches * B,), device=cuda, generator=gen, dtype=torch.int32)
+            pos = zipf_items(I, n_batches * B, gen, cuda)
+            neg = torch.randint(0, I, (n_batches * B,), device=cuda, generator=gen, dtype=torch.int32)
+            dev.reserve(B, d)
+
+            def step(s):
+                o = (s % n_batches) * B
+                dev.bpr_sgd_step(P, Q, b, users[o:o + B], pos[o:o + B], neg[o:o + B], lr, reg)
+            trainer = None
+        else:
+            from tfrec_amd.sharded import ShardedBprTrainer
+            trainer = ShardedBprTrainer(dev, U, I, d, lr, reg, seed=2018)
+            lo, hi = trainer.user_range
+            users = (torch.randint(0, hi - lo, (n_batches * B,), device=cuda, generator=gen, dtype=torch.int32) + lo)
+            pos = zipf_items(I, n_batches * B, gen, cuda)
+            neg = torch.randint(0, I, (n_batches * B,), device=cuda, generator=gen, dtype=torch.int32)
+
+            def step(s):
+                o = (s % n_batches) * B
+                trainer.step(users[o:o + B], pos[o:o + B], neg[o:o + B])
+
+        def barrier():
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+        for s in range(args.warmup):
+            step(s)
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        for s in range(args.steps):
+            step(args.warmup + s)
+        e1.record(stream)
+        barrier()
+        wall = time.perf_counter() - t0
+        dev_ms = e0.elapsed_time(e1)
+        if world > 1:
+            tmax = torch.tensor([wall], device=cuda, dtype=torch.float64)
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+            wall = float(tmax.item())
+        dev.synchronize()        # raises if any batch held an out-of-range index
+
+        ms_per_step = wall * 1e3 / args.steps
+        value = world * B * args.steps / wall
+        alg_bytes_per_triple = 24 * d + 28
+        out = {
+            "metric": "bpr_train_triples_per_s", "value": value, "unit": "triples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BPR-MF SGD step, synthetic %dM users x %dk items, d=%d fp32, %d-triple batch per GPU, "
+                                   "users uniform, positives Zipf(1.0), negatives uniform" % (U // 10**6, I // 1000, d, B),
+                       "users": U, "items": I, "factors": d, "batch_per_gpu": B, "global_batch": B * world,
+                       "lr": lr, "reg": reg, "resident_batches": n_batches,
+                       "parallelism": "single GPU" if world == 1 else "tables row-sharded over %d GPUs, all-to-all per step" % world},
+        }
+
+        if rank == 0 and world == 1:
+            # ---- roofline of the step's kernels: HIP events recorded by the library on its own stream
+            dev.set_profiling(True)
+            acc, reps = {}, 10
+            for s in range(reps):
+                step(s)
+                for name, t in dev.phase_times():
+                    acc[name] = acc.get(name, 0.0) + t / reps
+            dev.set_profiling(False)
+            step_ms = sum(acc.values())
+            dom = max(acc, key=acc.get)
+            achieved = B * alg_bytes_per_triple / (dev_ms / args.steps * 1e-3) / 1e9
+            out["roofline"] = {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "one BPR step = build_keys + radix sort + seg_tile/seg_fixup (user side) + seg_tile/seg_fixup (item side)",
+                "algorithmic_bytes_per_triple": alg_bytes_per_triple,
+                "device_ms_per_step": dev_ms / args.steps,
+                "phases_ms": acc, "dominant_phase": dom,
+                "dominant_phase_algorithmic_GBs": B * (16 * d + 20) / (acc[dom] * 1e-3) / 1e9 if dom == "user_tile" else None,
+            }
+            # ---- the reference batch size (conf/BPR.ini: 512), launch-bound
+            e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            small = 512
+            for s in range(20):
+                dev.bpr_sgd_step(P, Q, b, users[s * small:(s + 1) * small], pos[s * small:(s + 1) * small], neg[s * small:(s + 1) * small], lr, reg)
+            e2.record(stream)
+            for s in range(200):
+                o = (s % 1000) * small
+                dev.bpr_sgd_step(P, Q, b, users[o:o + small], pos[o:o + small], neg[o:o + small], lr, reg)
+            e3.record(stream)
+            torch.cuda.synchronize()
+            out["reference_batch_512"] = {"triples_per_s": 200 * small / (e2.elapsed_time(e3) * 1e-3), "us_per_step": e2.elapsed_time(e3) * 1e3 / 200}
+
+            if not args.no_eval:
+                n = min(args.eval_users, U)
+                k = args.topk
+                eu = torch.arange(n, device=cuda, dtype=torch.int32)
+                deg = 20
+                indptr = torch.arange(0, deg * (U + 1), deg, device=cuda, dtype=torch.int64)
+                indices = torch.sort(torch.randint(0, I, (U, deg), device=cuda, generator=gen, dtype=torch.int32), dim=1).values.reshape(-1).contiguous()
+                tdeg = 3
+                tptr = torch.arange(0, tdeg * (U + 1), tdeg, device=cuda, dtype=torch.int64)
+                tidx = torch.sort(torch.randint(0, I, (U, tdeg), device=cuda, generator=gen, dtype=torch.int32), dim=1).values.reshape(-1).contiguous()
+                ev = {}
+                for mode, name in ((SCORE_F32, "f32"), (SCORE_BF16, "bf16")):
+                    dev.eval_fullrank(P, Q, b, eu, (indptr, indices), (tptr, tidx), k, mode=mode)      # warm-up, sizes the workspace
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    dev.eval_fullrank(P, Q, b, eu, (indptr, indices), (tptr, tidx), k, mode=mode)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t1
+                    tf = 2.0 * I * d * n / dt / 1e12
+                    ev[name] = {"users_per_s": n / dt, "ms": dt * 1e3, "users": n, "items": I, "topk": k,
+                                "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS[name], "unit": "TFLOP/s",
+                                             "frac": tf / MFMA_PEAK_TFLOPS[name]}}
+                out["eval"] = ev
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(U, I, d, 1 << 17, lr, reg)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

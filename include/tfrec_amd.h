@@ -63,6 +63,14 @@ int tfrec_ctx_error_flags(tfrec_ctx *ctx, uint32_t *h_flags, int clear);
  * evaluation of up to max_eval_users users at top-k k, so that later calls allocate nothing. */
 int tfrec_ctx_reserve(tfrec_ctx *ctx, int64_t max_batch, int d, int64_t max_eval_users, int k);
 int64_t tfrec_ctx_workspace_bytes(tfrec_ctx *ctx);
+/* Phase timing (no counterpart in the reference beyond its wall-clock `timer` decorator,
+ * utils/tools.py:27-36): when enabled, every training/evaluation call records HIP events on
+ * the context's stream between its kernels.  tfrec_ctx_phase_times waits for the last call
+ * and returns the duration in milliseconds of each phase of that call; tfrec_ctx_phase_name
+ * names phase i ("index", "user_tile", "user_fixup", "item_tile", "item_fixup", ...). */
+int tfrec_ctx_set_profiling(tfrec_ctx *ctx, int enable);
+int tfrec_ctx_phase_times(tfrec_ctx *ctx, float *h_ms, int max_phases, int *n_phases);
+const char *tfrec_ctx_phase_name(tfrec_ctx *ctx, int i);
 
 /* ---- device memory helpers (for callers without their own allocator) --------------------- */
 int tfrec_dev_malloc(tfrec_ctx *ctx, size_t bytes, void **d_ptr);

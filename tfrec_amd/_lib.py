@@ -29,6 +29,9 @@ SIGNATURES = {
     "tfrec_ctx_error_flags": (_int, [_p, C.POINTER(C.c_uint32), _int]),
     "tfrec_ctx_reserve": (_int, [_p, _i64, _int, _i64, _int]),
     "tfrec_ctx_workspace_bytes": (_i64, [_p]),
+    "tfrec_ctx_set_profiling": (_int, [_p, _int]),
+    "tfrec_ctx_phase_times": (_int, [_p, C.POINTER(C.c_float), _int, C.POINTER(_int)]),
+    "tfrec_ctx_phase_name": (C.c_char_p, [_p, _int]),
     "tfrec_dev_malloc": (_int, [_p, C.c_size_t, C.POINTER(_p)]),
     "tfrec_dev_free": (_int, [_p, _p]),
     "tfrec_memcpy_h2d": (_int, [_p, _p, _p, C.c_size_t]),

@@ -94,6 +94,8 @@ extern "C" int tfrec_ctx_destroy(tfrec_ctx *ctx)
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    for (hipEvent_t e : ctx->marks)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return TFREC_OK;
@@ -131,6 +133,44 @@ extern "C" int tfrec_ctx_synchronize(tfrec_ctx *ctx)
         return TFREC_EINDEX;
     }
     return TFREC_OK;
+}
+
+void tfrec_marks_reset(tfrec_ctx *ctx) { ctx->n_marks = 0; }
+
+void tfrec_mark(tfrec_ctx *ctx, const char *name)
+{
+    if (!ctx->profile || ctx->n_marks >= tfrec_ctx::MAX_MARKS) return;
+    const int i = ctx->n_marks;
+    if (!ctx->marks[i] && hipEventCreate(&ctx->marks[i]) != hipSuccess) return;
+    if (hipEventRecord(ctx->marks[i], ctx->stream) != hipSuccess) return;
+    ctx->mark_names[i] = name;
+    ctx->n_marks = i + 1;
+}
+
+extern "C" int tfrec_ctx_set_profiling(tfrec_ctx *ctx, int enable)
+{
+    TF_REQUIRE(ctx != nullptr, TFREC_EINVAL, "null context");
+    ctx->profile = enable != 0;
+    ctx->n_marks = 0;
+    return TFREC_OK;
+}
+
+extern "C" int tfrec_ctx_phase_times(tfrec_ctx *ctx, float *h_ms, int max_phases, int *n_phases)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_REQUIRE(h_ms && n_phases, TFREC_EINVAL, "null output");
+    int n = ctx->n_marks > 0 ? ctx->n_marks - 1 : 0;
+    if (n > max_phases) n = max_phases;
+    if (ctx->n_marks > 0) TF_HIP(hipEventSynchronize(ctx->marks[ctx->n_marks - 1]));
+    for (int i = 0; i < n; ++i) TF_HIP(hipEventElapsedTime(&h_ms[i], ctx->marks[i], ctx->marks[i + 1]));
+    *n_phases = n;
+    return TFREC_OK;
+}
+
+extern "C" const char *tfrec_ctx_phase_name(tfrec_ctx *ctx, int i)
+{
+    if (!ctx || i < 0 || i + 1 >= ctx->n_marks) return "";
+    return ctx->mark_names[i + 1];
 }
 
 size_t tfrec_step_need_bytes(int64_t B, int d);                                        // train.hip

@@ -52,7 +52,17 @@ struct tfrec_ctx {
     void *h_pinned = nullptr;    // small pinned staging buffer for host outputs
     size_t h_pinned_bytes = 0;
     int pinned_tab_k = 0;        // k for which the pinned 1/log2 table is filled
+    // optional phase timing: events recorded on the context's stream between the kernels of a call
+    bool profile = false;
+    static constexpr int MAX_MARKS = 16;
+    hipEvent_t marks[MAX_MARKS] = {};
+    const char *mark_names[MAX_MARKS] = {};
+    int n_marks = 0;
 };
+
+// Records a named timing mark on the stream when profiling is on (no-op otherwise).
+void tfrec_mark(tfrec_ctx *ctx, const char *name);
+void tfrec_marks_reset(tfrec_ctx *ctx);
 
 // Makes ctx's device current for the calling thread.
 int tfrec_ctx_enter(tfrec_ctx *ctx);

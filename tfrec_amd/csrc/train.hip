@@ -567,24 +567,30 @@ static bool all_aligned16(std::initializer_list<const void *> ps)
 
 template <class Pol>
 static int run_pass(tfrec_ctx *ctx, const Pol &pol, const StepWs &w, int64_t base, int64_t n, int64_t n_tiles, int blocks,
-                    bool with_loss_part)
+                    bool with_loss_part, const char *tile_name, const char *fix_name)
 {
     if (n <= 0) return TFREC_OK;
     seg_tile_kernel<Pol><<<blocks, 256, 0, ctx->stream>>>(pol, w.keys, w.vals, base, n, w.part_rows, w.part_sc, w.tile_flags,
                                                          with_loss_part ? w.loss_part : nullptr);
     TF_HIP(hipGetLastError());
+    tfrec_mark(ctx, tile_name);
     seg_fixup_kernel<Pol><<<blocks, 256, 0, ctx->stream>>>(pol, w.keys, base, n, w.part_rows, w.part_sc, w.tile_flags, n_tiles);
     TF_HIP(hipGetLastError());
+    tfrec_mark(ctx, fix_name);
     return TFREC_OK;
 }
 
 static int sort_batch(tfrec_ctx *ctx, const StepWs &w, const int32_t *users, const int32_t *pos, const int32_t *neg, int64_t B,
                       int64_t U, int64_t I, int end_bit)
 {
+    tfrec_marks_reset(ctx);
+    tfrec_mark(ctx, "start");
     build_keys_kernel<<<(int)((B + 255) / 256), 256, 0, ctx->stream>>>(users, pos, neg, B, (uint32_t)U, (uint32_t)I, w.keys_in,
                                                                       w.vals_in, w.pair, ctx->d_flags);
     TF_HIP(hipGetLastError());
-    return tfrec_sort_pairs(w.sort_tmp, w.sort_tmp_bytes, w.keys_in, w.keys, w.vals_in, w.vals, (size_t)3 * B, end_bit, ctx->stream);
+    TF_TRY(tfrec_sort_pairs(w.sort_tmp, w.sort_tmp_bytes, w.keys_in, w.keys, w.vals_in, w.vals, (size_t)3 * B, end_bit, ctx->stream));
+    tfrec_mark(ctx, "index");
+    return TFREC_OK;
 }
 
 extern "C" int tfrec_bpr_sgd_step(tfrec_ctx *ctx, float *d_P, float *d_Q, float *d_b, int64_t U, int64_t I, int d,
@@ -608,13 +614,13 @@ extern "C" int tfrec_bpr_sgd_step(tfrec_ctx *ctx, float *d_P, float *d_Q, float 
     const bool want_loss = d_loss != nullptr;
     return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC>() -> int {
         if (want_loss) {
-            TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, true>{a}, w, 0, B, w.n_tiles_u, w.blocks_u, true));
+            TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, true>{a}, w, 0, B, w.n_tiles_u, w.blocks_u, true, "user_tile", "user_fixup"));
             loss_finalize_kernel<2><<<1, 256, 0, ctx->stream>>>(w.loss_part, w.blocks_u, d_loss);
             TF_HIP(hipGetLastError());
         } else {
-            TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, false>{a}, w, 0, B, w.n_tiles_u, w.blocks_u, false));
+            TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, false>{a}, w, 0, B, w.n_tiles_u, w.blocks_u, false, "user_tile", "user_fixup"));
         }
-        return run_pass(ctx, BprItemPol<LPR, NCH, VEC>{a}, w, B, 2 * B, w.n_tiles_i, w.blocks_i, false);
+        return run_pass(ctx, BprItemPol<LPR, NCH, VEC>{a}, w, B, 2 * B, w.n_tiles_i, w.blocks_i, false, "item_tile", "item_fixup");
     });
 }
 
@@ -647,8 +653,8 @@ extern "C" int tfrec_apr_adagrad_step(tfrec_ctx *ctx, float *d_P, float *d_Q, fl
     const bool want_loss = d_loss != nullptr;
     return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC>() -> int {
         // phase 1: deltas
-        TF_TRY(run_pass(ctx, AprUser1Pol<LPR, NCH, VEC>{a}, w, 0, B, w.n_tiles_u, w.blocks_u, false));
-        TF_TRY(run_pass(ctx, AprItem1Pol<LPR, NCH, VEC>{a}, w, B, 2 * B, w.n_tiles_i, w.blocks_i, false));
+        TF_TRY(run_pass(ctx, AprUser1Pol<LPR, NCH, VEC>{a}, w, 0, B, w.n_tiles_u, w.blocks_u, false, "delta_user_tile", "delta_user_fixup"));
+        TF_TRY(run_pass(ctx, AprItem1Pol<LPR, NCH, VEC>{a}, w, B, 2 * B, w.n_tiles_i, w.blocks_i, false, "delta_item_tile", "delta_item_fixup"));
         const int nb = (int)((2 * B + 255) / 256 < 512 ? (2 * B + 255) / 256 : 512);
         apr_bias_norm_kernel<<<nb, 256, 0, ctx->stream>>>(w.keys, B, 2 * B, (uint32_t)U, d_db, w.loss_part);
         TF_HIP(hipGetLastError());
@@ -656,15 +662,16 @@ extern "C" int tfrec_apr_adagrad_step(tfrec_ctx *ctx, float *d_P, float *d_Q, fl
         TF_HIP(hipGetLastError());
         apr_bias_scale_kernel<<<(int)((2 * B + 255) / 256), 256, 0, ctx->stream>>>(w.keys, B, 2 * B, (uint32_t)U, d_db, w.scalars, eps);
         TF_HIP(hipGetLastError());
+        tfrec_mark(ctx, "delta_bias_norm");
         // phase 2: Adagrad step at (Theta, delta)
         if (want_loss) {
-            TF_TRY(run_pass(ctx, AprUser2Pol<LPR, NCH, VEC, true>{a}, w, 0, B, w.n_tiles_u, w.blocks_u, true));
+            TF_TRY(run_pass(ctx, AprUser2Pol<LPR, NCH, VEC, true>{a}, w, 0, B, w.n_tiles_u, w.blocks_u, true, "user_tile", "user_fixup"));
             loss_finalize_kernel<3><<<1, 256, 0, ctx->stream>>>(w.loss_part, w.blocks_u, w.scalars + 4);
             TF_HIP(hipGetLastError());
         } else {
-            TF_TRY(run_pass(ctx, AprUser2Pol<LPR, NCH, VEC, false>{a}, w, 0, B, w.n_tiles_u, w.blocks_u, false));
+            TF_TRY(run_pass(ctx, AprUser2Pol<LPR, NCH, VEC, false>{a}, w, 0, B, w.n_tiles_u, w.blocks_u, false, "user_tile", "user_fixup"));
         }
-        TF_TRY(run_pass(ctx, AprItem2Pol<LPR, NCH, VEC>{a}, w, B, 2 * B, w.n_tiles_i, w.blocks_i, false));
+        TF_TRY(run_pass(ctx, AprItem2Pol<LPR, NCH, VEC>{a}, w, B, 2 * B, w.n_tiles_i, w.blocks_i, false, "item_tile", "item_fixup"));
         if (want_loss) {
             // the third number is a mean over B*d entries
             apr_loss_out_kernel<<<1, 1, 0, ctx->stream>>>(w.scalars + 4, d_loss, 1.0 / ((double)B * (double)d));

@@ -127,6 +127,16 @@ class Device:
     def workspace_bytes(self):
         return int(self.lib.tfrec_ctx_workspace_bytes(self.h))
 
+    def set_profiling(self, on=True):
+        _lib.check(self.lib.tfrec_ctx_set_profiling(self.h, 1 if on else 0))
+
+    def phase_times(self):
+        """[(phase name, milliseconds)] of the last profiled call (waits for it)."""
+        ms = (C.c_float * 16)()
+        n = C.c_int(0)
+        _lib.check(self.lib.tfrec_ctx_phase_times(self.h, ms, 16, C.byref(n)))
+        return [(self.lib.tfrec_ctx_phase_name(self.h, i).decode(), float(ms[i])) for i in range(n.value)]
+
     @property
     def stream(self):
         return self.lib.tfrec_ctx_stream(self.h)
