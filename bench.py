@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--topk", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
+    ap.add_argument("--extras", action="store_true", help="also time the reference batch size (512 triples per step)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -121,9 +122,20 @@ def main():
             neg = torch.randint(0, I, (n_batches * B,), device=cuda, generator=gen, dtype=torch.int32)
             dev.reserve(B, d)
 
-            def step(s):
+            def batch(s):
                 o = (s % n_batches) * B
-                dev.bpr_sgd_step(P, Q, b, users[o:o + B], pos[o:o + B], neg[o:o + B], lr, reg)
+                return users[o:o + B], pos[o:o + B], neg[o:o + B]
+
+            # the index work of batch s+1 is enqueued on the library's auxiliary stream before the row
+            # passes of batch s, so the two overlap; every step still does all of its own work
+            state = {"next": 0}
+            dev.prepare_batch(0, U, I, *batch(0))
+
+            def step(s):
+                k = state["next"]
+                dev.prepare_batch((k + 1) & 1, U, I, *batch(k + 1))
+                dev.bpr_sgd_step_prepared(k & 1, P, Q, b, lr, reg)
+                state["next"] = k + 1
             trainer = None
         else:
             from tfrec_amd.sharded import ShardedBprTrainer
@@ -176,10 +188,11 @@ def main():
 
         if rank == 0 and world == 1:
             # ---- roofline of the step's kernels: HIP events recorded by the library on its own stream
+            # (un-pipelined steps, so that the index phase is timed on the same stream as the row passes)
             dev.set_profiling(True)
             acc, reps = {}, 10
             for s in range(reps):
-                step(s)
+                dev.bpr_sgd_step(P, Q, b, *batch(s), lr, reg)
                 for name, t in dev.phase_times():
                     acc[name] = acc.get(name, 0.0) + t / reps
             dev.set_profiling(False)
@@ -195,18 +208,21 @@ def main():
                 "phases_ms": acc, "dominant_phase": dom,
                 "dominant_phase_algorithmic_GBs": B * (16 * d + 20) / (acc[dom] * 1e-3) / 1e9 if dom == "user_tile" else None,
             }
-            # ---- the reference batch size (conf/BPR.ini: 512), launch-bound
-            e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            small = 512
-            for s in range(20):
-                dev.bpr_sgd_step(P, Q, b, users[s * small:(s + 1) * small], pos[s * small:(s + 1) * small], neg[s * small:(s + 1) * small], lr, reg)
-            e2.record(stream)
-            for s in range(200):
-                o = (s % 1000) * small
-                dev.bpr_sgd_step(P, Q, b, users[o:o + small], pos[o:o + small], neg[o:o + small], lr, reg)
-            e3.record(stream)
-            torch.cuda.synchronize()
-            out["reference_batch_512"] = {"triples_per_s": 200 * small / (e2.elapsed_time(e3) * 1e-3), "us_per_step": e2.elapsed_time(e3) * 1e3 / 200}
+            if args.extras:
+                # the reference batch size (conf/BPR.ini: 512 triples per step): launch-bound
+                e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                small = 512
+                for s in range(20):
+                    o = s * small
+                    dev.bpr_sgd_step(P, Q, b, users[o:o + small], pos[o:o + small], neg[o:o + small], lr, reg)
+                e2.record(stream)
+                for s in range(200):
+                    o = (s % 1000) * small
+                    dev.bpr_sgd_step(P, Q, b, users[o:o + small], pos[o:o + small], neg[o:o + small], lr, reg)
+                e3.record(stream)
+                torch.cuda.synchronize()
+                out["reference_batch_512"] = {"triples_per_s": 200 * small / (e2.elapsed_time(e3) * 1e-3),
+                                              "us_per_step": e2.elapsed_time(e3) * 1e3 / 200}
 
             if not args.no_eval:
                 n = min(args.eval_users, U)

@@ -103,6 +103,18 @@ int tfrec_bpr_sgd_step(tfrec_ctx *ctx, float *d_P, float *d_Q, float *d_b,
                        const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg, int64_t B,
                        float lr, float reg, double *d_loss);
 
+/* The same step with its index work (range check, two radix sorts) taken off the critical path.
+ * tfrec_batch_prepare sorts batch `slot` (0 or 1) on the context's auxiliary stream, beside
+ * whatever the main stream is running; tfrec_bpr_sgd_step_prepared then runs the row passes of
+ * that batch on the main stream and consumes the slot.  Typical loop: prepare(0, batch 0); for
+ * s: prepare((s+1)&1, batch s+1); step_prepared(s&1).  The index arrays of a batch must stay
+ * untouched until the step that consumes it has been enqueued.  Results are identical to
+ * tfrec_bpr_sgd_step on the same batch. */
+int tfrec_batch_prepare(tfrec_ctx *ctx, int slot, int64_t U, int64_t I,
+                        const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg, int64_t B);
+int tfrec_bpr_sgd_step_prepared(tfrec_ctx *ctx, int slot, float *d_P, float *d_Q, float *d_b,
+                                int64_t U, int64_t I, int d, float lr, float reg, double *d_loss);
+
 /* One APR minibatch step: both session calls of model/APR.py:163-164.
  *   1) delta <- eps * l2_normalize(d L_bpr / d Theta)   (model/APR.py:116-132; rows one by one,
  *      the bias gradient as one vector over all items)

@@ -93,6 +93,32 @@ def test_bpr_step_is_reproducible(dev):
         assert np.array_equal(x, y)
 
 
+def test_prepared_steps_equal_plain_steps(dev):
+    """Index preparation running ahead on the auxiliary stream changes nothing in the results."""
+    rng = np.random.default_rng(12)
+    U, I, d, B, steps = 3000, 2000, 64, 20000, 6
+    P = rng.uniform(-0.3, 0.3, (U, d)).astype(np.float32)
+    Q = rng.uniform(-0.3, 0.3, (I, d)).astype(np.float32)
+    b = np.zeros(I, np.float32)
+    batches = [[dev.array(rng.integers(0, n, B).astype(np.int32)) for n in (U, I, I)] for _ in range(steps)]
+    a = [dev.array(x) for x in (P, Q, b)]
+    for u, i, j in batches:
+        dev.bpr_sgd_step(*a, u, i, j, 0.01, 0.05)
+    c = [dev.array(x) for x in (P, Q, b)]
+    loss = dev.zeros(2, np.float64)
+    dev.prepare_batch(0, U, I, *batches[0])
+    for s in range(steps):
+        if s + 1 < steps:
+            dev.prepare_batch((s + 1) & 1, U, I, *batches[s + 1])
+        dev.bpr_sgd_step_prepared(s & 1, *c, 0.01, 0.05, loss if s == steps - 1 else None)
+    dev.synchronize()
+    for x, y in zip(a, c):
+        assert np.array_equal(x.numpy(), y.numpy())
+    assert loss.numpy()[0] > 0
+    with pytest.raises(ValueError):
+        dev.bpr_sgd_step_prepared(0, *c, 0.01, 0.05)        # the slot was consumed
+
+
 def test_bpr_empty_batch_and_bad_index(dev):
     P = np.ones((4, 8), np.float32); Q = np.ones((5, 8), np.float32); b = np.zeros(5, np.float32)
     e = np.zeros(0, np.int32)

@@ -41,6 +41,8 @@ SIGNATURES = {
     "tfrec_fill_const": (_int, [_p, _p, _i64, _f]),
     "tfrec_mf_predict": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _i64, _p]),
     "tfrec_bpr_sgd_step": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _i64, _f, _f, _p]),
+    "tfrec_batch_prepare": (_int, [_p, _int, _i64, _i64, _p, _p, _p, _i64]),
+    "tfrec_bpr_sgd_step_prepared": (_int, [_p, _int, _p, _p, _p, _i64, _i64, _int, _f, _f, _p]),
     "tfrec_apr_adagrad_step": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _i64,
                                       _f, _f, _f, _f, _p]),
     "tfrec_dns_select": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _i64, _int, _p]),

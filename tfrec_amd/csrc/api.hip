@@ -96,6 +96,13 @@ extern "C" int tfrec_ctx_destroy(tfrec_ctx *ctx)
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     for (hipEvent_t e : ctx->marks)
         if (e) (void)hipEventDestroy(e);
+    if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
+    if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
+    for (tfrec_batch_slot &sl : ctx->slots) {
+        if (sl.mem) (void)hipFree(sl.mem);
+        if (sl.ready) (void)hipEventDestroy(sl.ready);
+        if (sl.released) (void)hipEventDestroy(sl.released);
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return TFREC_OK;

@@ -41,6 +41,18 @@ void tfrec_set_error(const char *fmt, ...);
 // ------------------------------------------------------------------------------------------
 // context: a device, a stream, and one growable workspace carved by a bump allocator
 // ------------------------------------------------------------------------------------------
+// Sorted index arrays of one prepared batch (train.hip)
+struct tfrec_batch_slot {
+    char *mem = nullptr;
+    size_t bytes = 0;
+    int64_t B = -1, U = 0, I = 0;            // B < 0: nothing prepared
+    uint32_t *keys = nullptr, *vals = nullptr;   // [3B] sorted: user side [0,B), item side [B,3B)
+    uint2 *pair = nullptr;
+    hipEvent_t ready = nullptr;              // recorded on the auxiliary stream after preparation
+    hipEvent_t released = nullptr;           // recorded on the main stream after the step that consumed the slot
+    bool has_released = false;
+};
+
 struct tfrec_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -52,6 +64,9 @@ struct tfrec_ctx {
     void *h_pinned = nullptr;    // small pinned staging buffer for host outputs
     size_t h_pinned_bytes = 0;
     int pinned_tab_k = 0;        // k for which the pinned 1/log2 table is filled
+    tfrec_batch_slot slots[3];      // 0,1: pipelined batches; 2: private to the unpipelined steps
+    hipStream_t aux_stream = nullptr;   // index preparation runs here, beside the row passes
+    hipEvent_t fork_event = nullptr;
     // optional phase timing: events recorded on the context's stream between the kernels of a call
     bool profile = false;
     static constexpr int MAX_MARKS = 16;

@@ -20,7 +20,7 @@
 // A policy `Pol` supplies the arithmetic:
 //   struct Pol { enum { LPR, NCH, VEC }; using RowT = Row<LPR,NCH,VEC>;
 //     struct Occ;  struct Seg;  struct Loss;
-//     uint2 aux(uint32_t key, uint32_t val)                 -> two extra indices staged per entry
+//     uint4 entry(uint32_t key, uint32_t val, int64_t pos)  -> the entry staged in LDS; .x must be the key
 //     Occ  load_occ(uint4 entry, int gl)                    -> gathers of one occurrence
 //     Seg  load_seg(uint32_t key, int gl)                   -> the destination row(s)
 //     void compute(Seg&, const Occ&, uint4 entry, Acc<RowT>&, Loss&, int gl)
@@ -120,9 +120,7 @@ __global__ __launch_bounds__(256) void seg_tile_kernel(Pol pol, const uint32_t *
     for (int s = 0; s < EPL; ++s) {
         const int e = s * LPR + gl;
         if (e < cnt) {
-            const uint32_t k = keys[base + a + e], v = vals[base + a + e];
-            const uint2 ax = pol.aux(k, v);
-            ent[g][e] = make_uint4(k, v, ax.x, ax.y);
+            ent[g][e] = pol.entry(keys[base + a + e], vals[base + a + e], base + a + e);
         }
     }
     __syncthreads();
@@ -208,17 +206,28 @@ __global__ __launch_bounds__(256) void seg_fixup_kernel(Pol pol, const uint32_t 
     if (w < n_tiles && (tile_flags[w] & TAIL_BIT)) {
         const int64_t last = ((w + 1) * CH < n ? (w + 1) * CH : n) - 1;
         const uint32_t key = keys[base + last];
-        Acc<RowT> tot = part_load<RowT, LPR, NCH, VEC>(part_rows, part_sc, 2 * w + 1, gl);
+        // flags of the next FIX_SHORT tiles at once (independent loads), then the chain length among them
+        uint32_t fl[FIX_SHORT];
+#pragma unroll
+        for (int s = 0; s < FIX_SHORT; ++s) fl[s] = w + 1 + s < n_tiles ? (tile_flags[w + 1 + s] & 3u) : LEAD_END;
+        int len = 0;
         bool done = false;
-        int64_t m = w + 1;
-        for (int step = 0; step < FIX_SHORT; ++step, ++m) {
-            if (m >= n_tiles) { done = true; break; }          // cannot happen: the last tile never continues
-            const uint32_t f = tile_flags[m] & 3u;
-            if (f == LEAD_NONE) { done = true; break; }        // defensive: nothing to add
-            tot.add(part_load<RowT, LPR, NCH, VEC>(part_rows, part_sc, 2 * m, gl));
-            if (f == LEAD_END) { done = true; break; }
+#pragma unroll
+        for (int s = 0; s < FIX_SHORT; ++s) {
+            if (!done) {
+                if (fl[s] == LEAD_NONE) { done = true; }              // defensive: nothing to add
+                else { len = s + 1; if (fl[s] == LEAD_END) done = true; }
+            }
         }
         if (done) {
+            Acc<RowT> tot = part_load<RowT, LPR, NCH, VEC>(part_rows, part_sc, 2 * w + 1, gl);
+            Acc<RowT> pr[FIX_SHORT];
+#pragma unroll
+            for (int s = 0; s < FIX_SHORT; ++s)
+                if (s < len) pr[s] = part_load<RowT, LPR, NCH, VEC>(part_rows, part_sc, 2 * (w + 1 + s), gl);
+#pragma unroll
+            for (int s = 0; s < FIX_SHORT; ++s)
+                if (s < len) tot.add(pr[s]);
             pol.apply(key, nullptr, tot, gl);
         } else if (gl == 0) {
             long_w[atomicAdd(&long_n, 1)] = w;
@@ -230,38 +239,46 @@ __global__ __launch_bounds__(256) void seg_fixup_kernel(Pol pol, const uint32_t 
     for (int c = 0; c < n_long; ++c) {
         // chains are taken in ascending tile order so the result does not depend on who registered first
         int64_t wl = -1;
-        {
-            int64_t best = INT64_MAX;
-            for (int i = 0; i < n_long; ++i) {
-                const int64_t x = long_w[i];
-                int rank = 0;
-                for (int j = 0; j < n_long; ++j) rank += (long_w[j] < x);
-                if (rank == c) best = x;
-            }
-            wl = best;
+        for (int i = 0; i < n_long; ++i) {
+            const int64_t x = long_w[i];
+            int rank = 0;
+            for (int j = 0; j < n_long; ++j) rank += (long_w[j] < x);
+            if (rank == c) wl = x;
         }
         // length of the chain: first following tile whose lead partial ends the segment
         if (threadIdx.x == 0) first_end = INT32_MAX;
         __syncthreads();
         int L = 0;
-        for (int64_t r0 = 0;; r0 += 256) {
-            const int64_t idx = wl + 1 + r0 + threadIdx.x;
-            const bool end_here = idx >= n_tiles || (tile_flags[idx] & 3u) != LEAD_THROUGH;
-            if (end_here) atomicMin(&first_end, (int)(r0 + threadIdx.x));
+        for (int64_t r0 = 0;; r0 += 1024) {
+            int mine = INT32_MAX;
+#pragma unroll
+            for (int q = 3; q >= 0; --q) {
+                const int64_t off = r0 + q * 256 + threadIdx.x;
+                const int64_t idx = wl + 1 + off;
+                if (idx >= n_tiles || (tile_flags[idx] & 3u) != LEAD_THROUGH) mine = (int)off;
+            }
+            if (mine != INT32_MAX) atomicMin(&first_end, mine);
             __syncthreads();
             const int fe = first_end;
             __syncthreads();
             if (fe != INT32_MAX) { L = fe + 1; break; }
         }
         if (wl + L >= n_tiles) L = (int)(n_tiles - 1 - wl);
-        // group gi sums a contiguous share of the lead partials wl+1 .. wl+L, in tile order
+        // group g sums a contiguous share of the lead partials wl+1 .. wl+L in tile order, four loads in flight
         const int per = (L + GPB - 1) / GPB;
         Acc<RowT> part;
         part.clear();
         {
             const int lo = g * per, hi = (g + 1) * per < L ? (g + 1) * per : L;
-            for (int t = lo; t < hi; ++t)
-                part.add(part_load<RowT, LPR, NCH, VEC>(part_rows, part_sc, 2 * (wl + 1 + t), gl));
+            int t = lo;
+            for (; t + 4 <= hi; t += 4) {
+                Acc<RowT> q0 = part_load<RowT, LPR, NCH, VEC>(part_rows, part_sc, 2 * (wl + 1 + t), gl);
+                Acc<RowT> q1 = part_load<RowT, LPR, NCH, VEC>(part_rows, part_sc, 2 * (wl + 2 + t), gl);
+                Acc<RowT> q2 = part_load<RowT, LPR, NCH, VEC>(part_rows, part_sc, 2 * (wl + 3 + t), gl);
+                Acc<RowT> q3 = part_load<RowT, LPR, NCH, VEC>(part_rows, part_sc, 2 * (wl + 4 + t), gl);
+                part.add(q0); part.add(q1); part.add(q2); part.add(q3);
+            }
+            for (; t < hi; ++t) part.add(part_load<RowT, LPR, NCH, VEC>(part_rows, part_sc, 2 * (wl + 1 + t), gl));
         }
         part.v.store(&red_rows[g][0], gl, LPR * NCH);
         if (gl == 0) red_sc[g] = make_float4(part.s0, part.s1, __int_as_float(part.cnt), 0.f);
@@ -273,8 +290,8 @@ __global__ __launch_bounds__(256) void seg_fixup_kernel(Pol pol, const uint32_t 
             for (int i = 0; i < GPB; ++i) {
                 Acc<RowT> pi;
                 pi.v = RowT::load(&red_rows[i][0], gl, LPR * NCH);
-                const float4 s = red_sc[i];
-                pi.s0 = s.x; pi.s1 = s.y; pi.cnt = __float_as_int(s.z);
+                const float4 sc4 = red_sc[i];
+                pi.s0 = sc4.x; pi.s1 = sc4.y; pi.cnt = __float_as_int(sc4.z);
                 tot.add(pi);
             }
             pol.apply(key, nullptr, tot, gl);

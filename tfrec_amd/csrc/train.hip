@@ -3,21 +3,29 @@
 // file holds the arithmetic (policies) and the C entry points.
 //
 // One step, for a batch of B triples (u, i, j):
-//   1. build_keys     3B (key, occurrence) pairs: key u for the user side, U+item for both
-//                     item sides; indices are range-checked (clamped + sticky flag)
-//   2. radix sort     by key: user occurrences land in [0,B), item occurrences in [B,3B)
-//   3. user pass      per triple: gather P[u], Q[i], Q[j] -> s = sigma(-x); sum the user
-//                     gradient per distinct u and update P[u] in place; leave s and the
-//                     pre-step copy of P[u] in a per-triple staging area
-//   4. item pass      per item occurrence: gather the staged s and P[u] -> sum the item
-//                     gradient per distinct item and update Q, b in place
-// Step 4 reads only the staging area, never P, so every gradient is taken at the pre-step
+//   1. index (can run ahead on a second stream, see tfrec_batch_prepare)
+//        3B (key, occurrence) pairs: key u for the user side, U+item for both item sides,
+//        range-checked (clamped + sticky flag), then ONE stable radix sort by key: user
+//        occurrences land in [0,B), item occurrences in [B,3B)
+//   2. user pass   gather P[u], Q[i], Q[j] -> s = sigma(-x); sum the user gradient per distinct
+//                  u and update P[u] in place; leave s and the pre-step P[u] of every triple in
+//                  a staging area
+//   3. item pass   per item occurrence: gather the staged s and P[u] -> sum the item gradient
+//                  per distinct item and update Q, b in place
+// Step 3 reads only the staging area, never P, so every gradient is taken at the pre-step
 // parameters although both tables are updated in place.
 #include "seg_pass.hpp"
 
 // ------------------------------------------------------------------------------------------
 // keys
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t clamp_index(int32_t v, uint32_t n, bool *bad)
+{
+    if (v < 0) { *bad = true; return 0u; }
+    if ((uint32_t)v >= n) { *bad = true; return n - 1; }
+    return (uint32_t)v;
+}
+
 __global__ __launch_bounds__(256) void build_keys_kernel(const int32_t *__restrict__ users, const int32_t *__restrict__ pos,
                                                          const int32_t *__restrict__ neg, int64_t B, uint32_t U, uint32_t I,
                                                          uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
@@ -25,21 +33,14 @@ __global__ __launch_bounds__(256) void build_keys_kernel(const int32_t *__restri
 {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= B) return;
-    int32_t u = users[t], i = pos[t], j = neg[t];
-    const bool bad = u < 0 || (uint32_t)u >= U || i < 0 || (uint32_t)i >= I || j < 0 || (uint32_t)j >= I;
-    if (bad) {
-        atomicOr(flags, TFREC_FLAG_BAD_INDEX);
-        u = u < 0 ? 0 : ((uint32_t)u >= U ? (int32_t)(U - 1) : u);
-        i = i < 0 ? 0 : ((uint32_t)i >= I ? (int32_t)(I - 1) : i);
-        j = j < 0 ? 0 : ((uint32_t)j >= I ? (int32_t)(I - 1) : j);
-    }
-    keys[t] = (uint32_t)u;
+    bool bad = false;
+    const uint32_t u = clamp_index(users[t], U, &bad), i = clamp_index(pos[t], I, &bad), j = clamp_index(neg[t], I, &bad);
+    if (bad) atomicOr(flags, TFREC_FLAG_BAD_INDEX);
+    keys[t] = u;
     vals[t] = (uint32_t)t;
-    keys[B + 2 * t] = U + (uint32_t)i;
-    vals[B + 2 * t] = (uint32_t)(2 * t);
-    keys[B + 2 * t + 1] = U + (uint32_t)j;
-    vals[B + 2 * t + 1] = (uint32_t)(2 * t + 1);
-    pair[t] = make_uint2((uint32_t)i, (uint32_t)j);
+    reinterpret_cast<uint2 *>(keys + B)[t] = make_uint2(U + i, U + j);
+    reinterpret_cast<uint2 *>(vals + B)[t] = make_uint2((uint32_t)(2 * t), (uint32_t)(2 * t + 1));
+    pair[t] = make_uint2(i, j);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -65,7 +66,11 @@ struct BprUserPol {
     struct Occ { RowT p, qi, qj; float bi, bj; };
     struct Seg { RowT p; };
 
-    __device__ __forceinline__ uint2 aux(uint32_t, uint32_t val) const { return a.pair[val]; }
+    __device__ __forceinline__ uint4 entry(uint32_t key, uint32_t val, int64_t) const
+    {
+        const uint2 ij = a.pair[val];
+        return make_uint4(key, val, ij.x, ij.y);
+    }
     __device__ __forceinline__ Occ load_occ(uint4 en, int gl) const
     {
         Occ o;
@@ -116,7 +121,7 @@ struct BprItemPol {
     struct Occ { RowT p; float s; };
     struct Seg { RowT q; float bk; };
 
-    __device__ __forceinline__ uint2 aux(uint32_t, uint32_t) const { return make_uint2(0, 0); }
+    __device__ __forceinline__ uint4 entry(uint32_t key, uint32_t val, int64_t) const { return make_uint4(key, val, 0, 0); }
     __device__ __forceinline__ Occ load_occ(uint4 en, int gl) const
     {
         const uint32_t t = en.y >> 1;
@@ -184,7 +189,11 @@ struct AprUser1Pol {
     AprParams a;
     struct Occ { RowT p, qi, qj; float bi, bj; };
     struct Seg { int unused; };
-    __device__ __forceinline__ uint2 aux(uint32_t, uint32_t val) const { return a.pair[val]; }
+    __device__ __forceinline__ uint4 entry(uint32_t key, uint32_t val, int64_t) const
+    {
+        const uint2 ij = a.pair[val];
+        return make_uint4(key, val, ij.x, ij.y);
+    }
     __device__ __forceinline__ Occ load_occ(uint4 en, int gl) const
     {
         Occ o;
@@ -224,7 +233,7 @@ struct AprItem1Pol {
     AprParams a;
     struct Occ { RowT p; float s; };
     struct Seg { int unused; };
-    __device__ __forceinline__ uint2 aux(uint32_t, uint32_t) const { return make_uint2(0, 0); }
+    __device__ __forceinline__ uint4 entry(uint32_t key, uint32_t val, int64_t) const { return make_uint4(key, val, 0, 0); }
     __device__ __forceinline__ Occ load_occ(uint4 en, int gl) const
     {
         const uint32_t t = en.y >> 1;
@@ -261,7 +270,11 @@ struct AprUser2Pol {
     AprParams a;
     struct Occ { RowT p, dp, qi, qj, dqi, dqj; float bi, bj, dbi, dbj; };
     struct Seg { RowT p; };
-    __device__ __forceinline__ uint2 aux(uint32_t, uint32_t val) const { return a.pair[val]; }
+    __device__ __forceinline__ uint4 entry(uint32_t key, uint32_t val, int64_t) const
+    {
+        const uint2 ij = a.pair[val];
+        return make_uint4(key, val, ij.x, ij.y);
+    }
     __device__ __forceinline__ Occ load_occ(uint4 en, int gl) const
     {
         Occ o;
@@ -330,7 +343,7 @@ struct AprItem2Pol {
     AprParams a;
     struct Occ { RowT c; float s; };
     struct Seg { RowT q; float bk; };
-    __device__ __forceinline__ uint2 aux(uint32_t, uint32_t) const { return make_uint2(0, 0); }
+    __device__ __forceinline__ uint4 entry(uint32_t key, uint32_t val, int64_t) const { return make_uint4(key, val, 0, 0); }
     __device__ __forceinline__ Occ load_occ(uint4 en, int gl) const
     {
         const uint32_t t = en.y >> 1;
@@ -469,28 +482,61 @@ static int bits_for(uint64_t n)   // bits needed to represent values < n
     return b;
 }
 
+// The sorted index arrays of a batch live in a context-owned slot (not in the per-call
+// workspace) so that a batch can be prepared on the auxiliary stream while the previous step
+// still runs.
+static size_t slot_bytes(int64_t B, size_t *sort_bytes)
+{
+    *sort_bytes = tfrec_sort_temp_bytes((size_t)3 * B, 32);
+    return 4 * tf_align(12 * (size_t)B) + tf_align(8 * (size_t)B) + tf_align(*sort_bytes) + 4096;
+}
+
+static int slot_prepare(tfrec_ctx *ctx, tfrec_batch_slot &sl, hipStream_t stream, const int32_t *users, const int32_t *pos,
+                        const int32_t *neg, int64_t B, int64_t U, int64_t I)
+{
+    size_t sort_bytes = 0;
+    const size_t need = slot_bytes(B, &sort_bytes);
+    if (need > sl.bytes) {
+        // growing: nothing may still be reading the old block
+        TF_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->aux_stream) TF_HIP(hipStreamSynchronize(ctx->aux_stream));
+        if (sl.mem) TF_HIP(hipFree(sl.mem));
+        sl.mem = nullptr; sl.bytes = 0;
+        hipError_t e = hipMalloc((void **)&sl.mem, need + need / 8);
+        if (e != hipSuccess) { tfrec_set_error("batch slot allocation of %zu bytes failed: %s", need, hipGetErrorString(e)); return TFREC_ENOMEM; }
+        sl.bytes = need + need / 8;
+    }
+    char *p = sl.mem;
+    auto take = [&](size_t bytes) { char *r = p; p += tf_align(bytes); return r; };
+    uint32_t *keys_in = (uint32_t *)take(12 * (size_t)B), *vals_in = (uint32_t *)take(12 * (size_t)B);
+    sl.keys = (uint32_t *)take(12 * (size_t)B);
+    sl.vals = (uint32_t *)take(12 * (size_t)B);
+    sl.pair = (uint2 *)take(8 * (size_t)B);
+    void *sort_tmp = take(sort_bytes);
+    build_keys_kernel<<<(int)((B + 255) / 256), 256, 0, stream>>>(users, pos, neg, B, (uint32_t)U, (uint32_t)I, keys_in, vals_in,
+                                                                 sl.pair, ctx->d_flags);
+    TF_HIP(hipGetLastError());
+    TF_TRY(tfrec_sort_pairs(sort_tmp, sort_bytes, keys_in, sl.keys, vals_in, sl.vals, (size_t)3 * B,
+                            bits_for((uint64_t)U + (uint64_t)I), stream));
+    sl.B = B; sl.U = U; sl.I = I;
+    return TFREC_OK;
+}
+
 struct StepWs {
-    uint32_t *keys_in, *vals_in, *keys, *vals;
-    uint2 *pair;
     float *stage, *sbuf, *part_rows;
     float4 *part_sc;
     uint32_t *tile_flags;
     double *loss_part, *scalars;
-    void *sort_tmp;
-    size_t sort_tmp_bytes;
     int64_t n_tiles_u, n_tiles_i;
     int blocks_u, blocks_i;
 };
 
-static size_t step_ws_bytes(int64_t B, int d, const RowCfg &c, int end_bit, size_t *sort_bytes)
+static size_t step_ws_bytes(int64_t B, int d, const RowCfg &c)
 {
     const int CH = c.lpr > 32 ? c.lpr : 32;
     const int64_t tiles = (2 * B + CH - 1) / CH + 1;      // the larger (item) side
     const size_t rowf = (size_t)c.lpr * c.nch * c.vec;
-    *sort_bytes = tfrec_sort_temp_bytes((size_t)3 * B, end_bit);
     size_t s = 0;
-    s += 4 * tf_align(sizeof(uint32_t) * 3 * B);           // keys_in, vals_in, keys, vals
-    s += tf_align(sizeof(uint2) * B);
     s += tf_align(sizeof(float) * (size_t)B * d);          // stage
     s += tf_align(sizeof(float) * B);                      // sbuf
     s += tf_align(sizeof(float) * 2 * tiles * rowf);       // partial rows
@@ -498,7 +544,6 @@ static size_t step_ws_bytes(int64_t B, int d, const RowCfg &c, int end_bit, size
     s += tf_align(sizeof(uint32_t) * tiles);
     s += tf_align(sizeof(double) * 4 * (tiles + 8));       // loss partials (<= one per block)
     s += tf_align(sizeof(double) * 16);
-    s += tf_align(*sort_bytes);
     return s + 4096;
 }
 
@@ -507,29 +552,22 @@ size_t tfrec_step_need_bytes(int64_t B, int d)
 {
     RowCfg c;
     if (!pick_cfg(d, true, &c)) return 0;
-    size_t sb = 0, best = step_ws_bytes(B, d, c, 32, &sb);
+    size_t best = step_ws_bytes(B, d, c);
     RowCfg c1;
     if (pick_cfg(d | 1, false, &c1)) {      // the scalar fallback used for unaligned tables
         c1.nch = d <= 64 ? 1 : (d <= 128 ? 2 : 4);
-        const size_t alt = step_ws_bytes(B, d, c1, 32, &sb);
+        const size_t alt = step_ws_bytes(B, d, c1);
         best = alt > best ? alt : best;
     }
     return best;
 }
 
-static int step_ws_carve(tfrec_ctx *ctx, int64_t B, int d, const RowCfg &c, int end_bit, StepWs *w)
+static int step_ws_carve(tfrec_ctx *ctx, int64_t B, int d, const RowCfg &c, StepWs *w)
 {
-    size_t sort_bytes = 0;
-    const size_t need = step_ws_bytes(B, d, c, end_bit, &sort_bytes);
-    TF_TRY(tfrec_ws_require(ctx, need));
+    TF_TRY(tfrec_ws_require(ctx, ctx->ws_used + step_ws_bytes(B, d, c)));
     const int CH = c.lpr > 32 ? c.lpr : 32, GPB = 256 / c.lpr;
     const int64_t tiles = (2 * B + CH - 1) / CH + 1;
     const size_t rowf = (size_t)c.lpr * c.nch * c.vec;
-    w->keys_in = (uint32_t *)tfrec_ws_take(ctx, sizeof(uint32_t) * 3 * B);
-    w->vals_in = (uint32_t *)tfrec_ws_take(ctx, sizeof(uint32_t) * 3 * B);
-    w->keys = (uint32_t *)tfrec_ws_take(ctx, sizeof(uint32_t) * 3 * B);
-    w->vals = (uint32_t *)tfrec_ws_take(ctx, sizeof(uint32_t) * 3 * B);
-    w->pair = (uint2 *)tfrec_ws_take(ctx, sizeof(uint2) * B);
     w->stage = (float *)tfrec_ws_take(ctx, sizeof(float) * (size_t)B * d);
     w->sbuf = (float *)tfrec_ws_take(ctx, sizeof(float) * B);
     w->part_rows = (float *)tfrec_ws_take(ctx, sizeof(float) * 2 * tiles * rowf);
@@ -537,9 +575,7 @@ static int step_ws_carve(tfrec_ctx *ctx, int64_t B, int d, const RowCfg &c, int 
     w->tile_flags = (uint32_t *)tfrec_ws_take(ctx, sizeof(uint32_t) * tiles);
     w->loss_part = (double *)tfrec_ws_take(ctx, sizeof(double) * 4 * (tiles + 8));
     w->scalars = (double *)tfrec_ws_take(ctx, sizeof(double) * 16);
-    w->sort_tmp = tfrec_ws_take(ctx, sort_bytes);
-    w->sort_tmp_bytes = sort_bytes;
-    TF_REQUIRE(w->sort_tmp != nullptr, TFREC_ENOMEM, "internal: workspace carve failed");
+    TF_REQUIRE(w->scalars != nullptr, TFREC_ENOMEM, "internal: workspace carve failed");
     w->n_tiles_u = (B + CH - 1) / CH;
     w->n_tiles_i = (2 * B + CH - 1) / CH;
     w->blocks_u = (int)((w->n_tiles_u + GPB - 1) / GPB);
@@ -552,7 +588,7 @@ static int check_step_args(const void *P, const void *Q, const void *b, int64_t 
 {
     TF_REQUIRE(P && Q && b, TFREC_EINVAL, "null table pointer");
     TF_REQUIRE(U > 0 && I > 0 && d > 0, TFREC_EINVAL, "bad table shape U=%lld I=%lld d=%d", (long long)U, (long long)I, d);
-    TF_REQUIRE((uint64_t)U + (uint64_t)I < (1ull << 32), TFREC_EUNSUP, "U+I must be below 2^32");
+    TF_REQUIRE((uint64_t)U + (uint64_t)I < (1ull << 32) && U < (1ll << 31) && I < (1ll << 31), TFREC_EUNSUP, "U+I must be below 2^32");
     TF_REQUIRE(B >= 0 && B < (1ll << 30), TFREC_EINVAL, "batch size %lld out of range", (long long)B);
     TF_REQUIRE(B == 0 || (u && i && j), TFREC_EINVAL, "null index pointer");
     return TFREC_OK;
@@ -566,31 +602,44 @@ static bool all_aligned16(std::initializer_list<const void *> ps)
 }
 
 template <class Pol>
-static int run_pass(tfrec_ctx *ctx, const Pol &pol, const StepWs &w, int64_t base, int64_t n, int64_t n_tiles, int blocks,
-                    bool with_loss_part, const char *tile_name, const char *fix_name)
+static int run_pass(tfrec_ctx *ctx, const Pol &pol, const StepWs &w, const uint32_t *keys, const uint32_t *vals, int64_t base,
+                    int64_t n, int64_t n_tiles, int blocks, bool with_loss_part, const char *tile_name, const char *fix_name)
 {
     if (n <= 0) return TFREC_OK;
-    seg_tile_kernel<Pol><<<blocks, 256, 0, ctx->stream>>>(pol, w.keys, w.vals, base, n, w.part_rows, w.part_sc, w.tile_flags,
+    seg_tile_kernel<Pol><<<blocks, 256, 0, ctx->stream>>>(pol, keys, vals, base, n, w.part_rows, w.part_sc, w.tile_flags,
                                                          with_loss_part ? w.loss_part : nullptr);
     TF_HIP(hipGetLastError());
     tfrec_mark(ctx, tile_name);
-    seg_fixup_kernel<Pol><<<blocks, 256, 0, ctx->stream>>>(pol, w.keys, base, n, w.part_rows, w.part_sc, w.tile_flags, n_tiles);
+    seg_fixup_kernel<Pol><<<blocks, 256, 0, ctx->stream>>>(pol, keys, base, n, w.part_rows, w.part_sc, w.tile_flags, n_tiles);
     TF_HIP(hipGetLastError());
     tfrec_mark(ctx, fix_name);
     return TFREC_OK;
 }
 
-static int sort_batch(tfrec_ctx *ctx, const StepWs &w, const int32_t *users, const int32_t *pos, const int32_t *neg, int64_t B,
-                      int64_t U, int64_t I, int end_bit)
+// the row passes of one BPR step over an already sorted batch
+static int bpr_passes(tfrec_ctx *ctx, const tfrec_batch_slot &sl, float *d_P, float *d_Q, float *d_b, int64_t U, int d,
+                      float lr, float reg, double *d_loss)
 {
-    tfrec_marks_reset(ctx);
-    tfrec_mark(ctx, "start");
-    build_keys_kernel<<<(int)((B + 255) / 256), 256, 0, ctx->stream>>>(users, pos, neg, B, (uint32_t)U, (uint32_t)I, w.keys_in,
-                                                                      w.vals_in, w.pair, ctx->d_flags);
-    TF_HIP(hipGetLastError());
-    TF_TRY(tfrec_sort_pairs(w.sort_tmp, w.sort_tmp_bytes, w.keys_in, w.keys, w.vals_in, w.vals, (size_t)3 * B, end_bit, ctx->stream));
-    tfrec_mark(ctx, "index");
-    return TFREC_OK;
+    const int64_t B = sl.B;
+    RowCfg cfg;
+    TF_REQUIRE(pick_cfg(d, all_aligned16({d_P, d_Q}), &cfg), TFREC_EUNSUP, "factor size d=%d is not supported (max 256)", d);
+    StepWs w;
+    TF_TRY(step_ws_carve(ctx, B, d, cfg, &w));
+    BprParams a{d_P, d_Q, d_b, w.stage, w.sbuf, sl.pair, (uint32_t)U, d, d / cfg.vec, lr, reg};
+    const bool want_loss = d_loss != nullptr;
+    return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC>() -> int {
+        if (want_loss) {
+            TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, true>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, true,
+                            "user_tile", "user_fixup"));
+            loss_finalize_kernel<2><<<1, 256, 0, ctx->stream>>>(w.loss_part, w.blocks_u, d_loss);
+            TF_HIP(hipGetLastError());
+        } else {
+            TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, false>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, false,
+                            "user_tile", "user_fixup"));
+        }
+        return run_pass(ctx, BprItemPol<LPR, NCH, VEC>{a}, w, sl.keys, sl.vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false, "item_tile",
+                        "item_fixup");
+    });
 }
 
 extern "C" int tfrec_bpr_sgd_step(tfrec_ctx *ctx, float *d_P, float *d_Q, float *d_b, int64_t U, int64_t I, int d,
@@ -603,25 +652,54 @@ extern "C" int tfrec_bpr_sgd_step(tfrec_ctx *ctx, float *d_P, float *d_Q, float 
         if (d_loss) TF_HIP(hipMemsetAsync(d_loss, 0, 2 * sizeof(double), ctx->stream));
         return TFREC_OK;
     }
-    RowCfg cfg;
-    TF_REQUIRE(pick_cfg(d, all_aligned16({d_P, d_Q}), &cfg), TFREC_EUNSUP, "factor size d=%d is not supported (max 256)", d);
-    const int end_bit = bits_for((uint64_t)U + (uint64_t)I);
-    StepWs w;
-    TF_TRY(step_ws_carve(ctx, B, d, cfg, end_bit, &w));
-    TF_TRY(sort_batch(ctx, w, d_users, d_pos, d_neg, B, U, I, end_bit));
+    tfrec_marks_reset(ctx);
+    tfrec_mark(ctx, "start");
+    tfrec_batch_slot &sl = ctx->slots[2];      // private slot of the unpipelined entry points, main stream only
+    TF_TRY(slot_prepare(ctx, sl, ctx->stream, d_users, d_pos, d_neg, B, U, I));
+    tfrec_mark(ctx, "index");
+    return bpr_passes(ctx, sl, d_P, d_Q, d_b, U, d, lr, reg, d_loss);
+}
 
-    BprParams a{d_P, d_Q, d_b, w.stage, w.sbuf, w.pair, (uint32_t)U, d, d / cfg.vec, lr, reg};
-    const bool want_loss = d_loss != nullptr;
-    return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC>() -> int {
-        if (want_loss) {
-            TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, true>{a}, w, 0, B, w.n_tiles_u, w.blocks_u, true, "user_tile", "user_fixup"));
-            loss_finalize_kernel<2><<<1, 256, 0, ctx->stream>>>(w.loss_part, w.blocks_u, d_loss);
-            TF_HIP(hipGetLastError());
-        } else {
-            TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, false>{a}, w, 0, B, w.n_tiles_u, w.blocks_u, false, "user_tile", "user_fixup"));
-        }
-        return run_pass(ctx, BprItemPol<LPR, NCH, VEC>{a}, w, B, 2 * B, w.n_tiles_i, w.blocks_i, false, "item_tile", "item_fixup");
-    });
+extern "C" int tfrec_batch_prepare(tfrec_ctx *ctx, int slot, int64_t U, int64_t I, const int32_t *d_users, const int32_t *d_pos,
+                                   const int32_t *d_neg, int64_t B)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_REQUIRE(slot == 0 || slot == 1, TFREC_EINVAL, "slot must be 0 or 1");
+    TF_REQUIRE(U > 0 && I > 0 && U < (1ll << 31) && I < (1ll << 31), TFREC_EINVAL, "bad table shape");
+    TF_REQUIRE(B >= 1 && B < (1ll << 30) && d_users && d_pos && d_neg, TFREC_EINVAL, "bad batch");
+    if (!ctx->aux_stream) TF_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    tfrec_batch_slot &sl = ctx->slots[slot];
+    if (!sl.ready) TF_HIP(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
+    if (!sl.released) TF_HIP(hipEventCreateWithFlags(&sl.released, hipEventDisableTiming));
+    // the index arrays of this slot may still be read by the step that used it last
+    if (sl.has_released) TF_HIP(hipStreamWaitEvent(ctx->aux_stream, sl.released, 0));
+    // the caller's index arrays were produced on the main stream
+    if (!ctx->fork_event) TF_HIP(hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
+    TF_HIP(hipEventRecord(ctx->fork_event, ctx->stream));
+    TF_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->fork_event, 0));
+    sl.B = -1;
+    TF_TRY(slot_prepare(ctx, sl, ctx->aux_stream, d_users, d_pos, d_neg, B, U, I));
+    TF_HIP(hipEventRecord(sl.ready, ctx->aux_stream));
+    return TFREC_OK;
+}
+
+extern "C" int tfrec_bpr_sgd_step_prepared(tfrec_ctx *ctx, int slot, float *d_P, float *d_Q, float *d_b, int64_t U, int64_t I,
+                                           int d, float lr, float reg, double *d_loss)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_REQUIRE(slot == 0 || slot == 1, TFREC_EINVAL, "slot must be 0 or 1");
+    tfrec_batch_slot &sl = ctx->slots[slot];
+    TF_REQUIRE(sl.B >= 1, TFREC_EINVAL, "slot %d holds no prepared batch", slot);
+    TF_REQUIRE(sl.U == U && sl.I == I, TFREC_EINVAL, "slot %d was prepared for a %lldx%lld model", slot, (long long)sl.U, (long long)sl.I);
+    TF_TRY(check_step_args(d_P, d_Q, d_b, U, I, d, d_P, d_P, d_P, sl.B));
+    TF_HIP(hipStreamWaitEvent(ctx->stream, sl.ready, 0));
+    tfrec_marks_reset(ctx);
+    tfrec_mark(ctx, "start");
+    const int rc = bpr_passes(ctx, sl, d_P, d_Q, d_b, U, d, lr, reg, d_loss);
+    TF_HIP(hipEventRecord(sl.released, ctx->stream));
+    sl.has_released = true;
+    sl.B = -1;      // consumed
+    return rc;
 }
 
 extern "C" int tfrec_apr_adagrad_step(tfrec_ctx *ctx, float *d_P, float *d_Q, float *d_b, float *d_accP, float *d_accQ,
@@ -639,39 +717,47 @@ extern "C" int tfrec_apr_adagrad_step(tfrec_ctx *ctx, float *d_P, float *d_Q, fl
     RowCfg cfg;
     TF_REQUIRE(pick_cfg(d, all_aligned16({d_P, d_Q, d_accP, d_accQ, d_dP, d_dQ}), &cfg), TFREC_EUNSUP,
                "factor size d=%d is not supported (max 256)", d);
-    const int end_bit = bits_for((uint64_t)U + (uint64_t)I);
+    tfrec_marks_reset(ctx);
+    tfrec_mark(ctx, "start");
+    tfrec_batch_slot &sl = ctx->slots[2];
+    TF_TRY(slot_prepare(ctx, sl, ctx->stream, d_users, d_pos, d_neg, B, U, I));
+    tfrec_mark(ctx, "index");
     StepWs w;
-    TF_TRY(step_ws_carve(ctx, B, d, cfg, end_bit, &w));
-    TF_TRY(sort_batch(ctx, w, d_users, d_pos, d_neg, B, U, I, end_bit));
+    TF_TRY(step_ws_carve(ctx, B, d, cfg, &w));
 
     AprParams a{};
     a.P = d_P; a.Q = d_Q; a.b = d_b; a.accP = d_accP; a.accQ = d_accQ; a.accb = d_accb;
     a.dP = d_dP; a.dQ = d_dQ; a.db = d_db;
-    a.stage = w.stage; a.sbuf = w.sbuf; a.pair = w.pair; a.users = d_users;
+    a.stage = w.stage; a.sbuf = w.sbuf; a.pair = sl.pair; a.users = d_users;
     a.U = (uint32_t)U; a.d = d; a.nchunk = d / cfg.vec;
     a.lr = lr; a.reg_coef = (float)(4.0 * (double)reg / ((double)B * (double)d)); a.reg_adv = reg_adv; a.eps = eps;
     const bool want_loss = d_loss != nullptr;
     return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC>() -> int {
         // phase 1: deltas
-        TF_TRY(run_pass(ctx, AprUser1Pol<LPR, NCH, VEC>{a}, w, 0, B, w.n_tiles_u, w.blocks_u, false, "delta_user_tile", "delta_user_fixup"));
-        TF_TRY(run_pass(ctx, AprItem1Pol<LPR, NCH, VEC>{a}, w, B, 2 * B, w.n_tiles_i, w.blocks_i, false, "delta_item_tile", "delta_item_fixup"));
+        TF_TRY(run_pass(ctx, AprUser1Pol<LPR, NCH, VEC>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, false,
+                        "delta_user_tile", "delta_user_fixup"));
+        TF_TRY(run_pass(ctx, AprItem1Pol<LPR, NCH, VEC>{a}, w, sl.keys, sl.vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false,
+                        "delta_item_tile", "delta_item_fixup"));
         const int nb = (int)((2 * B + 255) / 256 < 512 ? (2 * B + 255) / 256 : 512);
-        apr_bias_norm_kernel<<<nb, 256, 0, ctx->stream>>>(w.keys, B, 2 * B, (uint32_t)U, d_db, w.loss_part);
+        apr_bias_norm_kernel<<<nb, 256, 0, ctx->stream>>>(sl.keys, B, 2 * B, (uint32_t)U, d_db, w.loss_part);
         TF_HIP(hipGetLastError());
         loss_finalize_kernel<1><<<1, 256, 0, ctx->stream>>>(w.loss_part, nb, w.scalars);
         TF_HIP(hipGetLastError());
-        apr_bias_scale_kernel<<<(int)((2 * B + 255) / 256), 256, 0, ctx->stream>>>(w.keys, B, 2 * B, (uint32_t)U, d_db, w.scalars, eps);
+        apr_bias_scale_kernel<<<(int)((2 * B + 255) / 256), 256, 0, ctx->stream>>>(sl.keys, B, 2 * B, (uint32_t)U, d_db, w.scalars, eps);
         TF_HIP(hipGetLastError());
         tfrec_mark(ctx, "delta_bias_norm");
         // phase 2: Adagrad step at (Theta, delta)
         if (want_loss) {
-            TF_TRY(run_pass(ctx, AprUser2Pol<LPR, NCH, VEC, true>{a}, w, 0, B, w.n_tiles_u, w.blocks_u, true, "user_tile", "user_fixup"));
+            TF_TRY(run_pass(ctx, AprUser2Pol<LPR, NCH, VEC, true>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, true,
+                            "user_tile", "user_fixup"));
             loss_finalize_kernel<3><<<1, 256, 0, ctx->stream>>>(w.loss_part, w.blocks_u, w.scalars + 4);
             TF_HIP(hipGetLastError());
         } else {
-            TF_TRY(run_pass(ctx, AprUser2Pol<LPR, NCH, VEC, false>{a}, w, 0, B, w.n_tiles_u, w.blocks_u, false, "user_tile", "user_fixup"));
+            TF_TRY(run_pass(ctx, AprUser2Pol<LPR, NCH, VEC, false>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, false,
+                            "user_tile", "user_fixup"));
         }
-        TF_TRY(run_pass(ctx, AprItem2Pol<LPR, NCH, VEC>{a}, w, B, 2 * B, w.n_tiles_i, w.blocks_i, false, "item_tile", "item_fixup"));
+        TF_TRY(run_pass(ctx, AprItem2Pol<LPR, NCH, VEC>{a}, w, sl.keys, sl.vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false, "item_tile",
+                        "item_fixup"));
         if (want_loss) {
             // the third number is a mean over B*d entries
             apr_loss_out_kernel<<<1, 1, 0, ctx->stream>>>(w.scalars + 4, d_loss, 1.0 / ((double)B * (double)d));

@@ -158,6 +158,17 @@ class Device:
         _lib.check(self.lib.tfrec_bpr_sgd_step(self.h, _ptr(P), _ptr(Q), _ptr(b), U, I, d, _ptr(users), _ptr(pos), _ptr(neg), B,
                                                float(lr), float(reg), _ptr(loss)))
 
+    def prepare_batch(self, slot, U, I, users, pos, neg):
+        """Sorts a batch on the auxiliary stream (overlaps the row passes of the running step)."""
+        B = _shape(users)[0]
+        _lib.check(self.lib.tfrec_batch_prepare(self.h, int(slot), int(U), int(I), _ptr(users), _ptr(pos), _ptr(neg), B))
+
+    def bpr_sgd_step_prepared(self, slot, P, Q, b, lr, reg, loss=None):
+        U, d = _shape(P)
+        I = _shape(Q)[0]
+        _lib.check(self.lib.tfrec_bpr_sgd_step_prepared(self.h, int(slot), _ptr(P), _ptr(Q), _ptr(b), U, I, d, float(lr), float(reg),
+                                                        _ptr(loss)))
+
     def apr_adagrad_step(self, P, Q, b, accP, accQ, accb, dP, dQ, db, users, pos, neg, lr, reg, reg_adv, eps, loss=None):
         """Both session calls of model/APR.py:163-164.  ``loss``: optional device float64[3]."""
         U, d = _shape(P)

@@ -35,7 +35,9 @@ def main():
     torch.cuda.set_device(0)
     cuda = torch.device("cuda:0")
     gen = torch.Generator(device=cuda); gen.manual_seed(2018)
-    dev = Device(0, stream=torch.cuda.current_stream().cuda_stream)
+    stream = torch.cuda.Stream(device=cuda)
+    torch.cuda.set_stream(stream)
+    dev = Device(0, stream=stream.cuda_stream)
     P = (torch.rand(a.U, a.d, device=cuda, generator=gen) - 0.5) * 0.1
     Q = (torch.rand(a.I, a.d, device=cuda, generator=gen) - 0.5) * 0.1
     b = torch.zeros(a.I, device=cuda)
@@ -56,7 +58,19 @@ def main():
         for s in range(a.steps):
             step(s)
         e1.record(); torch.cuda.synchronize()
+        ms_plain = e0.elapsed_time(e1) / a.steps
+
+        def batch(s):
+            o = (s % 4) * B
+            return users[o:o + B], pos[o:o + B], neg[o:o + B]
+        dev.prepare_batch(0, a.U, a.I, *batch(0))
+        e0.record()
+        for s in range(a.steps):
+            dev.prepare_batch((s + 1) & 1, a.U, a.I, *batch(s + 1))
+            dev.bpr_sgd_step_prepared(s & 1, P, Q, b, 0.01, 0.05)
+        e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.steps
+        print(f"B={B}: plain {ms_plain:.3f} ms/step, pipelined {ms:.3f} ms/step")
         rate = B / ms * 1e3
         alg = (24 * a.d + 28) * rate / 1e12
         dev.set_profiling(True)
