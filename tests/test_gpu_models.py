@@ -1,0 +1,184 @@
+"""GPU tests of the model / evaluator plug-in surface (the reference's API for this path):
+BPR, DNSBPR and APR recommenders trained through the HIP library against the same schedule
+driven through the CPU oracle, the dense evaluator drop-in, and run_model.py end to end."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import ROOT, csr_from_pairs
+
+pytestmark = pytest.mark.gpu
+
+
+class _Log:
+    def __init__(self):
+        self.lines = []
+
+    def info(self, msg):
+        self.lines.append(msg)
+
+
+class _DS:
+    def __init__(self, train, test):
+        self.train_matrix, self.test_matrix = train, test
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from tfrec_amd.device import Device
+    d = Device(0)
+    yield d
+    d.close()
+
+
+def ml100k(golden_ml100k):
+    g = golden_ml100k
+    U, I = g["P"].shape[0], g["Q"].shape[0]
+    return _DS(csr_from_pairs(g["train_u"], g["train_i"], U, I), csr_from_pairs(g["test_u"], g["test_i"], U, I))
+
+
+def synthetic(seed, U=120, I=90):
+    rng = np.random.default_rng(seed)
+    rows, cols, trows, tcols = [], [], [], []
+    for u in range(U):
+        c = rng.permutation(I)[: int(rng.integers(3, 14))]
+        rows += [u] * (len(c) - 1); cols += c[:-1].tolist(); trows.append(u); tcols.append(int(c[-1]))
+    tr = sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(U, I)); tr.sort_indices()
+    te = sp.csr_matrix((np.ones(len(trows)), (trows, tcols)), shape=(U, I)); te.sort_indices()
+    return _DS(tr, te)
+
+
+def test_bpr_ml100k_two_epochs_match_the_oracle_schedule(dev, oracle, golden_ml100k):
+    """conf/BPR.ini on ML-100k with d=64: same seed, same sampler, same batch order; parameters
+    after two epochs (314 steps) and the metrics agree with the oracle-driven run."""
+    from tfrec_amd.evaluator import FoldOutEvaluator
+    from tfrec_amd.model import BPR
+    ds = ml100k(golden_ml100k)
+    ev = FoldOutEvaluator(ds.train_matrix, ds.test_matrix, top_k=50)
+    cfg = {"factors_num": 64, "lr": 0.01, "reg": 0.05, "epochs": 2, "batch_size": 512}
+    BPR.logger = _Log()
+    np.random.seed(2018)
+    model = BPR(dev, cfg, ds, ev)
+    P, Q, b = model.mf.parameters()
+    assert P.shape == (943, 64) and abs(P).max() <= 0.05 and not b.any()
+    model.train_model()
+    lines = BPR.logger.lines
+    assert lines[0].startswith("Precision@1:1:50") and len(lines) == 3
+    got = np.array([float(x) for x in lines[-1].split("\t")[1:]], dtype=np.float32)
+    assert got.shape == (250,)
+
+    rs = np.random.RandomState(2018)
+    user_pos = oracle.csr_to_user_dict(ds.train_matrix)
+    ws = oracle.Workspace(943, 1682, 64)
+    for ep in range(2):
+        u, i, j = oracle.bpr_epoch_triples(rs, user_pos, 1682)
+        for idx in oracle.batch_order(rs, len(u), 512):
+            oracle.bpr_step(P, Q, b, u[idx], i[idx], j[idx], 0.01, 0.05, ws=ws)
+    P1, Q1, b1 = model.mf.parameters()
+    for a, c in ((P1, P), (Q1, Q), (b1, b)):
+        np.testing.assert_allclose(a, c, rtol=2e-4, atol=2e-6)
+    users = np.array(sorted(ev.user_pos_test.keys()), np.int32)
+    mean, _, _ = oracle.eval_fullrank(P1, Q1, b1, users, (ds.train_matrix.indptr, ds.train_matrix.indices),
+                                      (ds.test_matrix.indptr, ds.test_matrix.indices), 50, score_mode=1)
+    np.testing.assert_allclose(got.reshape(5, 50), mean, rtol=1e-6, atol=1e-7)
+    # the dense route (_predict + eval_rating_matrix) gives the same numbers up to score rounding
+    from tfrec_amd.evaluator.backend import eval_rating_matrix
+    R = model._predict().astype(np.float32)
+    keep = R.copy()
+    dense = eval_rating_matrix(R, ev.user_pos_train, ev.user_pos_test, top_k=50)
+    assert np.array_equal(R, keep)                     # the caller's matrix is left alone
+    np.testing.assert_allclose(dense, mean, rtol=2e-3, atol=2e-3)
+
+
+def test_dense_evaluator_drop_in_matches_reference_vectors(golden_eval):
+    from tfrec_amd.evaluator.backend import eval_rating_matrix
+    g = {k.split("/", 1)[1]: v for k, v in golden_eval.items() if k.startswith("subset/")}
+    R = (g["P"] @ g["Q"].T + g["b"]).astype(np.float32)
+    tr = {u: g["train_indices"][g["train_indptr"][u]:g["train_indptr"][u + 1]] for u in range(len(g["P"]))
+          if g["train_indptr"][u + 1] > g["train_indptr"][u]}
+    te = {int(u): g["test_indices"][g["test_indptr"][u]:g["test_indptr"][u + 1]] for u in g["test_users"]}
+    for k in g["k_list"]:
+        out = eval_rating_matrix(R, tr, te, top_k=int(k))
+        assert out.dtype == np.float32 and out.shape == (5, int(k))
+        assert np.array_equal(out, g["metrics_k%d" % k])
+    with pytest.raises(TypeError):
+        eval_rating_matrix(R.tolist(), tr, te)
+
+
+def test_dnsbpr_epoch(dev, oracle):
+    from tfrec_amd.evaluator import FoldOutEvaluator
+    from tfrec_amd.model import DNSBPR
+    ds = synthetic(1)
+    ev = FoldOutEvaluator(ds.train_matrix, ds.test_matrix, top_k=10)
+    cfg = {"factors_num": 20, "lr": 0.01, "reg": 0.05, "epochs": 1, "batch_size": 64, "neg_num": 15, "data_name": "unit"}
+    DNSBPR.logger = _Log()
+    np.random.seed(7)
+    model = DNSBPR(dev, cfg, ds, ev)
+    P, Q, b = model.mf.parameters()
+    np.random.seed(7)
+    it = model.get_training_data()
+    users, pos, neg = it.columns
+    # the oracle draws the same pools and picks the same negatives wherever the scores are not tied
+    rs = np.random.RandomState(7)
+    U, I = ds.train_matrix.shape
+    pools = []
+    for u, p in oracle.csr_to_user_dict(ds.train_matrix).items():
+        pools.append(oracle.choice_excluding(rs, I, 15 * len(p), p).reshape(len(p), 15))
+    pools = np.concatenate(pools).astype(np.int32)
+    ref, margin = oracle.dns_select(P, Q, b, users, pools)
+    ok = margin > 1e-6
+    assert ok.mean() > 0.95 and np.array_equal(neg[ok], ref[ok])
+    assert all(neg[t] in pools[t] for t in range(len(neg)))
+    for u, p, n in zip(users, pos, neg):
+        row = ds.train_matrix.indices[ds.train_matrix.indptr[u]:ds.train_matrix.indptr[u + 1]]
+        assert n not in row
+
+
+def test_apr_epoch_matches_the_oracle_schedule(dev, oracle, tmp_path):
+    from tfrec_amd.evaluator import FoldOutEvaluator
+    from tfrec_amd.model import APR
+    from tfrec_amd.utils import save_params
+    ds = synthetic(2)
+    U, I = ds.train_matrix.shape
+    rng = np.random.default_rng(3)
+    P = rng.uniform(-0.3, 0.3, (U, 20)).astype(np.float32); Q = rng.uniform(-0.3, 0.3, (I, 20)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, I).astype(np.float32)
+    pre = str(tmp_path / "pre.npz")
+    save_params(pre, P, Q, b)
+    ev = FoldOutEvaluator(ds.train_matrix, ds.test_matrix, top_k=10)
+    cfg = {"factors_num": 20, "lr": 0.05, "reg": 0.0, "reg_adv": 1, "eps": 0.05, "epochs": 1, "batch_size": 128, "pretrain_file": pre}
+    APR.logger = _Log()
+    np.random.seed(11)
+    model = APR(dev, cfg, ds, ev)
+    model.train_model()
+    assert APR.logger.lines[1].startswith("pretrain:") and len(APR.logger.lines) == 3
+    rs = np.random.RandomState(11)
+    aP, aQ, ab = [np.full_like(x, 0.1) for x in (P, Q, b)]
+    ws = oracle.Workspace(U, I, 20)
+    u, i, j = oracle.bpr_epoch_triples(rs, oracle.csr_to_user_dict(ds.train_matrix), I)
+    for idx in oracle.batch_order(rs, len(u), 128):
+        oracle.apr_step(P, Q, b, aP, aQ, ab, u[idx], i[idx], j[idx], 0.05, 0.0, 1.0, 0.05, ws=ws)
+    for got, want in zip(model.mf.parameters(), (P, Q, b)):
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-6)
+
+
+def test_run_model_end_to_end(tmp_path):
+    """run_model.py with the shipped ini layout: one epoch of BPR on ML-100k, one log line of 250 numbers."""
+    os.makedirs(tmp_path / "conf")
+    (tmp_path / "conf" / "BPR.ini").write_text("[hyperparameters]\nlr = 0.01\nreg = 0.05\nfactors_num = 20\nbatch_size = 512\nepochs = 1\n")
+    ini = open(os.path.join(ROOT, "tfrec.ini")).read().replace("./dataset/", os.path.join(ROOT, "dataset") + "/")
+    (tmp_path / "tfrec.ini").write_text(ini)
+    if not os.path.exists(os.path.join(ROOT, "dataset", "movielens-100k-train.txt")):
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "export_ml100k.py")])
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "run_model.py")], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if "epoch 0:" in l][-1]
+    vals = [float(x) for x in line.split("epoch 0:\t")[1].split("\t")]
+    assert len(vals) == 250 and 0.0 < vals[0] <= 1.0
+    logs = os.listdir(tmp_path / "log" / "ml100k" / "BPR")
+    assert len(logs) == 1 and logs[0].startswith("BPR_log_lr=0.01_reg=0.05_factors_num=20_batch_size=512_epochs=1_")

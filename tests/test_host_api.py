@@ -1,0 +1,106 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU, no library calls)."""
+import hashlib
+import os
+import pickle
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import csr_from_pairs
+from tfrec_amd.data import DataIterator
+from tfrec_amd.model.ModelFactory import parse_value
+from tfrec_amd.utils import argmax_top_k, csr_to_user_dict, random_choice, typeassert
+from tfrec_amd.utils.params_io import load_params, read_param_pickle_safely, save_params
+
+
+def test_sampler_and_iterator_reproduce_the_reference_epoch(golden_sampler, golden_ml100k):
+    """utils.random_choice + DataIterator under np.random.seed(2018) give the reference's triples,
+    batch order and batch count bit for bit (vectors made by the reference's own code)."""
+    g, m = golden_sampler, golden_ml100k
+    U, I = m["P"].shape[0], m["Q"].shape[0]
+    user_pos = csr_to_user_dict(csr_from_pairs(m["train_u"], m["train_i"], U, I))
+    all_items = np.arange(I)
+    np.random.seed(2018)
+    for ep in range(2):
+        users, pos, neg = [], [], []
+        for u, p in user_pos.items():
+            ng = random_choice(all_items, size=len(p), exclusion=p)
+            users += [u] * len(p); pos += p.tolist(); neg += ng.tolist()
+        assert np.array_equal(np.array(neg), g["epoch%d_neg" % ep].astype(np.int64))
+        it = DataIterator(users, pos, neg, batch_size=512, shuffle=True)
+        batches = list(it)
+        assert len(batches) == len(it) == int(g["epoch%d_n_batches" % ep])
+        assert len(batches[-1][0]) == int(g["epoch%d_last_len" % ep])
+        assert isinstance(batches[0][0], list)
+        flat = np.concatenate([np.array(bt, dtype=np.int32) for bt in batches], axis=1)
+        assert hashlib.sha256(flat.tobytes()).hexdigest() == str(g["epoch%d_batched_sha" % ep])
+        assert np.array_equal(np.array(batches[0], np.int32), g["epoch%d_first_batch" % ep])
+
+
+def test_iterator_epoch_arrays_match_iteration():
+    np.random.seed(5)
+    it = DataIterator(list(range(10)), list(range(10, 20)), batch_size=3, shuffle=True)
+    np.random.seed(9)
+    a = list(it)
+    np.random.seed(9)
+    cols, bounds = it.columns_in_epoch_order()
+    assert bounds == [0, 3, 6, 9, 10]
+    for k, bt in enumerate(a):
+        assert bt[0] == cols[0][bounds[k]:bounds[k + 1]].tolist() and bt[1] == cols[1][bounds[k]:bounds[k + 1]].tolist()
+    it2 = DataIterator(list(range(10)), batch_size=3, shuffle=False, drop_last=True)
+    assert list(it2) == [[0, 1, 2], [3, 4, 5], [6, 7, 8]] and len(it2) == 3
+    with pytest.raises(ValueError):
+        DataIterator([1, 2], batch_size=0)
+    with pytest.raises(AssertionError):
+        DataIterator([1, 2], [1], batch_size=1)
+
+
+def test_csr_to_user_dict_quirk(golden_sampler):
+    quirk = sp.csr_matrix((np.ones(4), ([1, 2, 2, 3], [0, 0, 3, 2])), shape=(4, 5))
+    assert sorted(csr_to_user_dict(quirk).keys()) == golden_sampler["quirk_kept_rows"].tolist()
+    with pytest.raises(TypeError):
+        csr_to_user_dict(np.zeros((2, 2)))
+
+
+def test_typeassert_and_argmax_top_k():
+    @typeassert(a=int, b=str)
+    def f(a, b="x", c=None):
+        return a
+    assert f(1) == 1 and f(1, b="y") == 1
+    with pytest.raises(TypeError):
+        f("1")
+    with pytest.raises(TypeError):
+        f(1, b=2)
+    # equal values: the LARGER index comes first, as heapq over (value, index) does in the reference
+    assert argmax_top_k(np.array([1.0, 3.0, 3.0, 2.0]), 3).tolist() == [2, 1, 3]
+
+
+def test_parse_value():
+    assert parse_value("0.1/16") == 0.1 / 16
+    assert parse_value("'\\t'") == "\t"
+    assert parse_value("dataset/ml100k_dnsbpr.pkl") == "dataset/ml100k_dnsbpr.pkl"
+    assert parse_value("512") == 512 and parse_value("[1, 2]") == [1, 2] and parse_value("-0.5") == -0.5
+    assert parse_value("__import__('os').system('true')") == "__import__('os').system('true')"
+
+
+def test_param_files(tmp_path):
+    rng = np.random.default_rng(0)
+    P, Q, b = rng.normal(size=(7, 4)).astype(np.float32), rng.normal(size=(5, 4)).astype(np.float32), rng.normal(size=5).astype(np.float32)
+    for name in ("m.npz", "m.pkl"):
+        path = str(tmp_path / name)
+        save_params(path, P, Q, b)
+        for trusted in (False, True):
+            got = load_params(path, trusted=trusted)
+            assert all(np.array_equal(x, y) for x, y in zip(got, (P, Q, b)))
+    # protocol-2 pickles keep array bytes as strings: read without unpickling as well
+    path = str(tmp_path / "old.pkl")
+    with open(path, "wb") as f:
+        pickle.dump([P, Q, b], f, protocol=2)
+    got = read_param_pickle_safely(path)
+    assert all(np.array_equal(x, y) for x, y in zip(got, (P, Q, b)))
+    bad = str(tmp_path / "bad.pkl")
+    with open(bad, "wb") as f:
+        pickle.dump([os.path.join, 1], f)
+    with pytest.raises(ValueError):
+        read_param_pickle_safely(bad)

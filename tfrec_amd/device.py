@@ -42,6 +42,10 @@ class DevArray:
         _lib.check(self.dev.lib.tfrec_memcpy_h2d(self.dev.h, self.ptr, host.ctypes.data, self.nbytes))
         return self
 
+    def view(self, lo, hi):
+        """Rows [lo, hi) as a non-owning array (the parent must outlive it)."""
+        return DevView(self, lo, hi)
+
     def free(self):
         if self.ptr and self.dev.h:
             self.dev.lib.tfrec_dev_free(self.dev.h, self.ptr)
@@ -54,11 +58,31 @@ class DevArray:
             pass
 
 
+class DevView:
+    """A row range of a DevArray; just a pointer and a shape."""
+
+    def __init__(self, parent, lo, hi):
+        if not (0 <= lo <= hi <= parent.shape[0]):
+            raise IndexError("view [%d,%d) of %d rows" % (lo, hi, parent.shape[0]))
+        row_bytes = parent.nbytes // max(parent.shape[0], 1)
+        self.parent = parent
+        self.dev = parent.dev
+        self.dtype = parent.dtype
+        self.shape = (hi - lo,) + parent.shape[1:]
+        self.nbytes = row_bytes * (hi - lo)
+        self.ptr = parent.ptr + row_bytes * lo
+
+    def numpy(self):
+        out = np.empty(self.shape, self.dtype)
+        _lib.check(self.dev.lib.tfrec_memcpy_d2h(self.dev.h, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+
 def _ptr(x):
     """Device pointer of a DevArray, a torch tensor, an int, or None."""
     if x is None:
         return None
-    if isinstance(x, DevArray):
+    if isinstance(x, (DevArray, DevView)):
         return x.ptr
     if isinstance(x, int):
         return x

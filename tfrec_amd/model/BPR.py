@@ -1,0 +1,65 @@
+"""BPR-MF (Rendle et al.), with the reference's class shape (model/BPR.py:16-85)."""
+import numpy as np
+
+from ..data import DataIterator
+from ..device import Device
+from ..utils import csr_to_user_dict, random_choice
+from .base import AbstractRecommender, MatrixFactorization
+
+
+class BPR(AbstractRecommender):
+    def __init__(self, sess, config, dataset, evaluator):
+        super(BPR, self).__init__(sess, config, dataset, evaluator)
+        train_matrix = dataset.train_matrix
+        self.users_num, self.items_num = train_matrix.shape
+        self.factors_num = config["factors_num"]
+        self.lr = config["lr"]
+        self.reg = config["reg"]
+        self.epochs = config["epochs"]
+        self.batch_size = config["batch_size"]
+        self.user_pos_train = csr_to_user_dict(train_matrix)
+        self.all_items = np.arange(self.items_num)
+        self.evaluator = evaluator
+        self.sess = sess if sess is not None else Device(0)
+        self.mf = MatrixFactorization(self.sess, self.users_num, self.items_num, self.factors_num, name=self.__class__.__name__)
+
+    # -- sampling: uniform non-positive per positive, users in dict order (model/BPR.py:50-62) --
+    def get_training_data(self):
+        users, pos_items, neg_items = [], [], []
+        for u, pos in self.user_pos_train.items():
+            neg = random_choice(self.all_items, size=len(pos), exclusion=pos)
+            users.append(np.full(len(pos), u, dtype=np.int32))
+            pos_items.append(np.asarray(pos, dtype=np.int32))
+            neg_items.append(neg.astype(np.int32))
+        return DataIterator(np.concatenate(users), np.concatenate(pos_items), np.concatenate(neg_items),
+                            batch_size=self.batch_size, shuffle=True)
+
+    def _train_epoch(self, train_data):
+        """One epoch of minibatch steps (model/BPR.py:68-72): the epoch's triples are uploaded once
+        in batch order and every batch is one tfrec_bpr_sgd_step on a slice of them."""
+        (users, pos, neg), bounds = train_data.columns_in_epoch_order()
+        dev = self.sess
+        du, dp, dn = dev.array(users, np.int32), dev.array(pos, np.int32), dev.array(neg, np.int32)
+        P, Q, b = self.mf.device_parameters()
+        for k in range(len(bounds) - 1):
+            lo, hi = bounds[k], bounds[k + 1]
+            dev.bpr_sgd_step(P, Q, b, du.view(lo, hi), dp.view(lo, hi), dn.view(lo, hi), self.lr, self.reg)
+        dev.synchronize()
+
+    def train_model(self):
+        self.logger.info(self.evaluator.metrics_info())
+        for epoch in range(self.epochs):
+            self._train_epoch(self.get_training_data())
+            result = self.evaluate_model()
+            self.logger.info("epoch %d:\t%s" % (epoch, result))
+
+    def device_factors(self):
+        return (self.sess,) + tuple(self.mf.device_parameters())
+
+    def _predict(self):
+        user_embedding, item_embedding, item_bias = self.mf.parameters()
+        return np.matmul(user_embedding, item_embedding.T) + item_bias
+
+    def evaluate_model(self):
+        result = self.evaluator.evaluate(self)
+        return '\t'.join([str(x) for x in result])

@@ -1,0 +1,77 @@
+"""Reading and writing the [P, Q, b] parameter triple.
+
+The reference saves it with pickle (model/DNSBPR.py:106-109) and loads it with pickle.load
+(model/APR.py:47-53).  Files written by this package are .npz (preferred) or the same pickle of
+three float32 arrays; a pickle that came from elsewhere (e.g. the reference's shipped
+dataset/ml100k_saved_model.pkl) is read WITHOUT unpickling: the opcode stream is only
+disassembled and the raw array bytes are lifted out of it.
+"""
+import pickle
+import pickletools
+
+import numpy as np
+
+
+def save_params(path, P, Q, b):
+    P, Q, b = [np.ascontiguousarray(x, dtype=np.float32) for x in (P, Q, b)]
+    if path.endswith(".npz"):
+        np.savez(path, P=P, Q=Q, b=b)
+    else:
+        with open(path, "wb") as fout:          # same container as the reference: a list of three arrays
+            pickle.dump([P, Q, b], fout)
+
+
+def read_param_pickle_safely(path):
+    """Three float32 arrays from a pickle of [ndarray, ndarray, ndarray] without executing it."""
+    with open(path, "rb") as fin:
+        raw = fin.read()
+    ints, shapes, blobs, dtypes = [], [], [], []
+    # An ndarray's state tuple is (version, shape, dtype, is_fortran, DATA): the payload is the
+    # bytes/str argument that follows the is_fortran flag (possibly after a memo fetch of
+    # _codecs.encode, which python-3 protocol-2 pickles wrap around a latin-1 text).
+    expect_data = False
+    payload_ops = ("BINBYTES", "SHORT_BINBYTES", "BINBYTES8", "BINSTRING", "SHORT_BINSTRING", "BINUNICODE", "SHORT_BINUNICODE",
+                   "BINUNICODE8")
+    for op, arg, _ in pickletools.genops(raw):
+        name = op.name
+        if expect_data and name in payload_ops:
+            blobs.append(arg.encode("latin-1") if isinstance(arg, str) else bytes(arg))
+            expect_data = False
+            continue
+        if name in ("NEWFALSE", "NEWTRUE"):
+            expect_data = True
+            continue
+        if not (expect_data and name in ("BINGET", "LONG_BINGET", "MEMOIZE", "BINPUT", "LONG_BINPUT")):
+            expect_data = False
+        if name in ("BININT", "BININT1", "BININT2", "LONG1", "INT"):
+            ints.append(int(arg))
+        elif name in ("TUPLE1", "TUPLE2", "TUPLE3"):
+            n = int(name[-1])
+            shapes.append(tuple(ints[-n:]) if len(ints) >= n else ())
+        elif name in ("BINUNICODE", "SHORT_BINUNICODE") and arg in ("f4", "f8"):
+            dtypes.append(arg)
+        elif name in ("GLOBAL", "STACK_GLOBAL") and arg and not (str(arg).startswith("numpy") or str(arg) == "_codecs encode"):
+            raise ValueError("%s references %r: not a plain numpy parameter pickle" % (path, arg))
+    if len(blobs) != 3:
+        raise ValueError("%s: expected three array payloads, found %d" % (path, len(blobs)))
+    item = 4 if (not dtypes or dtypes[0] == "f4") else 8
+    out = []
+    for blob in blobs:
+        n = len(blob) // item
+        match = [s for s in shapes if s and int(np.prod(s)) == n and 0 not in s]
+        if not match:
+            raise ValueError("%s: no shape matches a payload of %d elements" % (path, n))
+        out.append(np.frombuffer(blob, "<f%d" % item).reshape(match[0]).astype(np.float32))
+    return out
+
+
+def load_params(path, trusted=False):
+    """[P, Q, b].  .npz is read with numpy; a pickle is unpickled only if ``trusted`` (a file this
+    package wrote), otherwise it is parsed without execution."""
+    if path.endswith(".npz"):
+        z = np.load(path, allow_pickle=False)
+        return [z["P"], z["Q"], z["b"]]
+    if trusted:
+        with open(path, "rb") as fin:
+            return [np.asarray(x, dtype=np.float32) for x in pickle.load(fin)]
+    return read_param_pickle_safely(path)
