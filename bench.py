@@ -139,7 +139,7 @@ def main():
             trainer = None
         else:
             from tfrec_amd.sharded import ShardedBprTrainer
-            trainer = ShardedBprTrainer(dev, U, I, d, lr, reg, seed=2018)
+            trainer = ShardedBprTrainer(dev, U, I, d, lr, reg, seed=2018, device=cuda)
             lo, hi = trainer.user_range
             users = (torch.randint(0, hi - lo, (n_batches * B,), device=cuda, generator=gen, dtype=torch.int32) + lo)
             pos = zipf_items(I, n_batches * B, gen, cuda)

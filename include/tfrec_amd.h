@@ -83,6 +83,9 @@ int tfrec_memset_zero(tfrec_ctx *ctx, void *d_dst, size_t bytes);
 /* model/base/MatrixFactorization.py:17-21: tables ~ U(lo, hi) (reference: -0.05, 0.05), bias 0.
  * Counter-based generator: element n gets the n-th value of the stream named by seed. */
 int tfrec_fill_uniform(tfrec_ctx *ctx, float *d_x, int64_t n, float lo, float hi, uint64_t seed);
+/* The same stream starting at element first_index: a shard of a table gets exactly the values
+ * the whole table would get. */
+int tfrec_fill_uniform_at(tfrec_ctx *ctx, float *d_x, int64_t n, float lo, float hi, uint64_t seed, int64_t first_index);
 int tfrec_fill_const(tfrec_ctx *ctx, float *d_x, int64_t n, float value);
 
 /* model/base/MatrixFactorization.py:26-32 (predict): out[t] = <P[users[t]], Q[items[t]]> + b[items[t]] */
@@ -114,6 +117,23 @@ int tfrec_batch_prepare(tfrec_ctx *ctx, int slot, int64_t U, int64_t I,
                         const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg, int64_t B);
 int tfrec_bpr_sgd_step_prepared(tfrec_ctx *ctx, int slot, float *d_P, float *d_Q, float *d_b,
                                 int64_t U, int64_t I, int d, float lr, float reg, double *d_loss);
+
+/* The two halves of a step on row-sharded tables (no counterpart in the reference, which is a
+ * single process, run_model.py:14-16; the arithmetic is that of model/BPR.py:36-48).
+ * tfrec_bpr_grad_step: like tfrec_bpr_sgd_step on P (complete update: the caller routes every
+ * triple to the GPU that owns its user), but d_Qc/d_bc hold FETCHED COPIES of the Ic distinct item
+ * rows the batch touches (items are addressed by their slot in that copy); on return each row of
+ * d_Qc/d_bc holds the summed gradient of that item over this GPU's triples (including the l2
+ * term of every occurrence) instead of an updated row.
+ * tfrec_rows_sgd_apply: the owner side: Q[ids[t]] -= lr * grad_rows[t], b[ids[t]] -= lr *
+ * grad_b[t], rows that share an id summed first, in the order they appear (so summing the
+ * per-GPU sums in rank order is reproducible). */
+int tfrec_bpr_grad_step(tfrec_ctx *ctx, float *d_P, float *d_Qc, float *d_bc,
+                        int64_t U, int64_t Ic, int d,
+                        const int32_t *d_users, const int32_t *d_pos_slot, const int32_t *d_neg_slot, int64_t B,
+                        float lr, float reg, double *d_loss);
+int tfrec_rows_sgd_apply(tfrec_ctx *ctx, float *d_Q, float *d_b, int64_t I, int d,
+                         const int32_t *d_ids, const float *d_grad_rows, const float *d_grad_b, int64_t n, float lr);
 
 /* One APR minibatch step: both session calls of model/APR.py:163-164.
  *   1) delta <- eps * l2_normalize(d L_bpr / d Theta)   (model/APR.py:116-132; rows one by one,
@@ -155,6 +175,16 @@ int tfrec_score_topk(tfrec_ctx *ctx, const float *d_P, const float *d_Q, const f
                      const int32_t *d_eval_users, int64_t n,
                      const int64_t *d_train_indptr, const int32_t *d_train_indices,
                      int k, int score_mode, int32_t *d_out_ids, float *d_out_scores);
+
+/* The same for a GPU that holds only its own item shard (rows item_id_lo .. item_id_lo +
+ * n_shard_items of the full tables, stored from row 0) and receives the evaluated users' factor
+ * rows packed in list order: row r of d_P_rows belongs to user d_eval_users[r] (global id, used
+ * for the train CSR).  Reported ids are global. */
+int tfrec_score_topk_shard(tfrec_ctx *ctx, const float *d_P_rows, const float *d_Q_shard, const float *d_b_shard,
+                           int64_t n_shard_items, int64_t item_id_lo, int d,
+                           const int32_t *d_eval_users, int64_t n,
+                           const int64_t *d_train_indptr, const int32_t *d_train_indices,
+                           int k, int score_mode, int32_t *d_out_ids, float *d_out_scores);
 
 /* Merge G per-shard top-k lists [G,n,k] into the global top-k [n,k] under the same total
  * order (the all-gather merge of an item-sharded evaluation). */

@@ -38,15 +38,19 @@ SIGNATURES = {
     "tfrec_memcpy_d2h": (_int, [_p, _p, _p, C.c_size_t]),
     "tfrec_memset_zero": (_int, [_p, _p, C.c_size_t]),
     "tfrec_fill_uniform": (_int, [_p, _p, _i64, _f, _f, C.c_uint64]),
+    "tfrec_fill_uniform_at": (_int, [_p, _p, _i64, _f, _f, C.c_uint64, _i64]),
     "tfrec_fill_const": (_int, [_p, _p, _i64, _f]),
     "tfrec_mf_predict": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _i64, _p]),
     "tfrec_bpr_sgd_step": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _i64, _f, _f, _p]),
     "tfrec_batch_prepare": (_int, [_p, _int, _i64, _i64, _p, _p, _p, _i64]),
     "tfrec_bpr_sgd_step_prepared": (_int, [_p, _int, _p, _p, _p, _i64, _i64, _int, _f, _f, _p]),
+    "tfrec_bpr_grad_step": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _i64, _f, _f, _p]),
+    "tfrec_rows_sgd_apply": (_int, [_p, _p, _p, _i64, _int, _p, _p, _p, _i64, _f]),
     "tfrec_apr_adagrad_step": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _i64,
                                       _f, _f, _f, _f, _p]),
     "tfrec_dns_select": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _i64, _int, _p]),
     "tfrec_score_topk": (_int, [_p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _i64, _p, _p, _int, _int, _p, _p]),
+    "tfrec_score_topk_shard": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _i64, _p, _p, _int, _int, _p, _p]),
     "tfrec_topk_merge": (_int, [_p, _p, _p, _int, _i64, _int, _p, _p]),
     "tfrec_topk_fill_masked": (_int, [_p, _p, _p, _i64, _int, _p, _p]),
     "tfrec_topk_dense": (_int, [_p, _p, _i64, _i64, _int, _p, _p, _p, _p, _p]),

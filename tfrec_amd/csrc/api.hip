@@ -256,11 +256,11 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
     return x ^ (x >> 31);
 }
 
-__global__ void fill_uniform_kernel(float *x, int64_t n, float lo, float hi, uint64_t seed)
+__global__ void fill_uniform_kernel(float *x, int64_t n, float lo, float hi, uint64_t seed, uint64_t first)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint64_t r = splitmix64(seed * 0x100000001b3ull + (uint64_t)i);
+        const uint64_t r = splitmix64(seed * 0x100000001b3ull + first + (uint64_t)i);
         const float u = (float)(r >> 40) * (1.0f / 16777216.0f);   // 24 bits -> [0,1)
         x[i] = fmaf(u, hi - lo, lo);
     }
@@ -279,7 +279,17 @@ extern "C" int tfrec_fill_uniform(tfrec_ctx *ctx, float *d_x, int64_t n, float l
     TF_TRY(tfrec_ctx_enter(ctx));
     TF_REQUIRE(n >= 0 && (d_x || n == 0), TFREC_EINVAL, "bad buffer");
     if (n == 0) return TFREC_OK;
-    fill_uniform_kernel<<<fill_grid(n), 256, 0, ctx->stream>>>(d_x, n, lo, hi, seed);
+    fill_uniform_kernel<<<fill_grid(n), 256, 0, ctx->stream>>>(d_x, n, lo, hi, seed, 0);
+    TF_HIP(hipGetLastError());
+    return TFREC_OK;
+}
+
+extern "C" int tfrec_fill_uniform_at(tfrec_ctx *ctx, float *d_x, int64_t n, float lo, float hi, uint64_t seed, int64_t first_index)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_REQUIRE(n >= 0 && first_index >= 0 && (d_x || n == 0), TFREC_EINVAL, "bad buffer");
+    if (n == 0) return TFREC_OK;
+    fill_uniform_kernel<<<fill_grid(n), 256, 0, ctx->stream>>>(d_x, n, lo, hi, seed, (uint64_t)first_index);
     TF_HIP(hipGetLastError());
     return TFREC_OK;
 }

@@ -137,6 +137,8 @@ struct ScoreArgs {
     const int64_t *train_indptr;
     const int32_t *train_indices;
     int k;
+    int p_compact;             // 1: row r of P belongs to users[r]; 0: P is the full table, indexed by user id
+    int64_t id_offset;         // added to shard-relative item positions to form the reported (global) ids
     uint64_t *lists;           // [gridDim.y, n, CAP]
     int32_t *out_ids;          // [gridDim.y, n, k]
     float *out_scores;         // [gridDim.y, n, k]
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void score_topk_kernel(ScoreArgs a)
     if (lane < 32) { cnt[wave * 32 + uj] = 0; ver[wave * 32 + uj] = 0; tau[wave * 32 + uj] = uvalid ? -INFINITY : INFINITY; }
 
     // user factors -> B-operand fragments, resident for the whole scan
-    const float *prow = a.P + (size_t)user * a.d;
+    const float *prow = a.P + (size_t)(a.p_compact ? urc : (int64_t)user) * a.d;
     float pf[BF16 ? 1 : D / 2];
     bf16x8 pb[BF16 ? D / 16 : 1];
     if constexpr (BF16) {
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256) void score_topk_kernel(ScoreArgs a)
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
             if (mx > th) {
-                const int32_t id0 = (int32_t)(a.item_lo + it0 + step * TI + sb * 32 + 4 * h);
+                const int32_t id0 = (int32_t)(a.id_offset + a.item_lo + it0 + step * TI + sb * 32 + 4 * h);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     if (acc[r] > th) {
@@ -587,12 +589,12 @@ static int plan_score(const float *d_Q, int d, int64_t item_lo, int64_t item_hi,
 static int score_topk_impl(tfrec_ctx *ctx, const float *d_P, const float *d_Q, const float *d_b, int64_t I, int d,
                            int64_t item_lo, int64_t item_hi, const int32_t *d_eval_users, int64_t n,
                            const int64_t *d_train_indptr, const int32_t *d_train_indices, int k, int score_mode,
-                           int32_t *d_out_ids, float *d_out_scores)
+                           int32_t *d_out_ids, float *d_out_scores, int p_compact = 0, int64_t id_offset = 0)
 {
     TF_REQUIRE(d_P && d_Q && d_b, TFREC_EINVAL, "null table pointer");
     TF_REQUIRE(0 <= item_lo && item_lo <= item_hi && item_hi <= I, TFREC_EINVAL, "bad item range [%lld,%lld) of %lld",
                (long long)item_lo, (long long)item_hi, (long long)I);
-    TF_REQUIRE(I < (1ll << 31), TFREC_EUNSUP, "item ids must fit in int32");
+    TF_REQUIRE(I + id_offset < (1ll << 31), TFREC_EUNSUP, "item ids must fit in int32");
     TF_REQUIRE(n >= 0 && k >= 1, TFREC_EINVAL, "bad n or k");
     TF_REQUIRE(score_mode == TFREC_SCORE_F32 || score_mode == TFREC_SCORE_BF16, TFREC_EINVAL, "unknown score mode %d", score_mode);
     TF_REQUIRE((d_train_indptr == nullptr) == (d_train_indices == nullptr), TFREC_EINVAL, "train CSR needs both arrays");
@@ -634,6 +636,9 @@ static int score_topk_impl(tfrec_ctx *ctx, const float *d_P, const float *d_Q, c
         a.item_lo = item_lo;
         a.n_items = n_items;
         a.split_items = split_items;
+        a.P = p_compact ? d_P + (size_t)u0 * d : d_P;
+        a.p_compact = p_compact;
+        a.id_offset = id_offset;
         a.users = d_eval_users + u0;
         a.n = nn;
         a.train_indptr = d_train_indptr;
@@ -658,6 +663,17 @@ extern "C" int tfrec_score_topk(tfrec_ctx *ctx, const float *d_P, const float *d
     TF_TRY(tfrec_ctx_enter(ctx));
     return score_topk_impl(ctx, d_P, d_Q, d_b, I, d, item_lo, item_hi, d_eval_users, n, d_train_indptr, d_train_indices, k,
                            score_mode, d_out_ids, d_out_scores);
+}
+
+extern "C" int tfrec_score_topk_shard(tfrec_ctx *ctx, const float *d_P_rows, const float *d_Q_shard, const float *d_b_shard,
+                                      int64_t n_shard_items, int64_t item_id_lo, int d, const int32_t *d_eval_users, int64_t n,
+                                      const int64_t *d_train_indptr, const int32_t *d_train_indices, int k, int score_mode,
+                                      int32_t *d_out_ids, float *d_out_scores)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_REQUIRE(item_id_lo >= 0, TFREC_EINVAL, "negative id offset");
+    return score_topk_impl(ctx, d_P_rows, d_Q_shard, d_b_shard, n_shard_items, d, 0, n_shard_items, d_eval_users, n, d_train_indptr,
+                           d_train_indices, k, score_mode, d_out_ids, d_out_scores, 1, item_id_lo);
 }
 
 extern "C" int tfrec_topk_fill_masked(tfrec_ctx *ctx, int32_t *d_ids, const int32_t *d_eval_users, int64_t n, int k,

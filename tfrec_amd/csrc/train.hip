@@ -112,7 +112,10 @@ struct BprUserPol {
     }
 };
 
-template <int LPR_, int NCH_, int VEC_>
+// GRAD = false: apply the SGD update to Q, b.  GRAD = true: leave the summed gradient of every
+// distinct item in its Q row and b entry instead (the tables then hold fetched copies of rows
+// owned by other GPUs, and the sums travel back to the owners).
+template <int LPR_, int NCH_, int VEC_, bool GRAD = false>
 struct BprItemPol {
     enum { LPR = LPR_, NCH = NCH_, VEC = VEC_ };
     using RowT = Row<LPR_, NCH_, VEC_>;
@@ -149,11 +152,71 @@ struct BprItemPol {
         const RowT q = seg ? seg->q : RowT::load(row, gl, a.nchunk);
         const float bk = seg ? seg->bk : a.b[it];
         const float nreg = (float)acc.cnt * a.reg, lr = a.lr;
-        const RowT out = q.map2(acc.v, [=](float qv, float av) { return fmaf(-lr, fmaf(nreg, qv, -av), qv); });
-        out.store(row, gl, a.nchunk);
-        if (gl == 0) a.b[it] = fmaf(-lr, fmaf(nreg, bk, -acc.s0), bk);
+        if constexpr (GRAD) {
+            const RowT out = q.map2(acc.v, [=](float qv, float av) { return fmaf(nreg, qv, -av); });
+            out.store(row, gl, a.nchunk);
+            if (gl == 0) a.b[it] = fmaf(nreg, bk, -acc.s0);
+        } else {
+            const RowT out = q.map2(acc.v, [=](float qv, float av) { return fmaf(-lr, fmaf(nreg, qv, -av), qv); });
+            out.store(row, gl, a.nchunk);
+            if (gl == 0) a.b[it] = fmaf(-lr, fmaf(nreg, bk, -acc.s0), bk);
+        }
     }
 };
+
+// Q[id] -= lr * (sum of the gradient rows sent for id), b likewise: the owner side of a sharded step
+struct RowsApplyParams {
+    float *Q, *b;
+    const float *grad_rows, *grad_b;
+    int d, nchunk;
+    float lr;
+};
+
+template <int LPR_, int NCH_, int VEC_>
+struct RowsApplyPol {
+    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_ };
+    using RowT = Row<LPR_, NCH_, VEC_>;
+    using Loss = LossAcc<0>;
+    RowsApplyParams a;
+    struct Occ { RowT g; float gb; };
+    struct Seg { RowT q; float bk; };
+    __device__ __forceinline__ uint4 entry(uint32_t key, uint32_t val, int64_t) const { return make_uint4(key, val, 0, 0); }
+    __device__ __forceinline__ Occ load_occ(uint4 en, int gl) const
+    {
+        return Occ{RowT::load(a.grad_rows + (size_t)en.y * a.d, gl, a.nchunk), a.grad_b[en.y]};
+    }
+    __device__ __forceinline__ Seg load_seg(uint32_t key, int gl) const
+    {
+        return Seg{RowT::load(a.Q + (size_t)key * a.d, gl, a.nchunk), a.b[key]};
+    }
+    __device__ __forceinline__ void compute(Seg &, const Occ &o, uint4, Acc<RowT> &acc, Loss &, int) const
+    {
+        acc.v = acc.v + o.g;
+        acc.s0 += o.gb;
+        acc.cnt += 1;
+    }
+    __device__ __forceinline__ void apply(uint32_t key, const Seg *seg, const Acc<RowT> &acc, int gl) const
+    {
+        float *row = a.Q + (size_t)key * a.d;
+        const RowT q = seg ? seg->q : RowT::load(row, gl, a.nchunk);
+        const float bk = seg ? seg->bk : a.b[key];
+        const float lr = a.lr;
+        q.map2(acc.v, [=](float qv, float gv) { return fmaf(-lr, gv, qv); }).store(row, gl, a.nchunk);
+        if (gl == 0) a.b[key] = fmaf(-lr, acc.s0, bk);
+    }
+};
+
+__global__ __launch_bounds__(256) void iota_keys_kernel(const int32_t *__restrict__ ids, int64_t n, uint32_t I,
+                                                        uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                        uint32_t *__restrict__ flags)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    bool bad = false;
+    keys[t] = clamp_index(ids[t], I, &bad);
+    vals[t] = (uint32_t)t;
+    if (bad) atomicOr(flags, TFREC_FLAG_BAD_INDEX);
+}
 
 // ------------------------------------------------------------------------------------------
 // APR policies.  model/APR.py:64-136.
@@ -618,7 +681,7 @@ static int run_pass(tfrec_ctx *ctx, const Pol &pol, const StepWs &w, const uint3
 
 // the row passes of one BPR step over an already sorted batch
 static int bpr_passes(tfrec_ctx *ctx, const tfrec_batch_slot &sl, float *d_P, float *d_Q, float *d_b, int64_t U, int d,
-                      float lr, float reg, double *d_loss)
+                      float lr, float reg, double *d_loss, bool item_grad_only = false)
 {
     const int64_t B = sl.B;
     RowCfg cfg;
@@ -637,8 +700,66 @@ static int bpr_passes(tfrec_ctx *ctx, const tfrec_batch_slot &sl, float *d_P, fl
             TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, false>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, false,
                             "user_tile", "user_fixup"));
         }
+        if (item_grad_only)
+            return run_pass(ctx, BprItemPol<LPR, NCH, VEC, true>{a}, w, sl.keys, sl.vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false,
+                            "item_tile", "item_fixup");
         return run_pass(ctx, BprItemPol<LPR, NCH, VEC>{a}, w, sl.keys, sl.vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false, "item_tile",
                         "item_fixup");
+    });
+}
+
+extern "C" int tfrec_bpr_grad_step(tfrec_ctx *ctx, float *d_P, float *d_Qc, float *d_bc, int64_t U, int64_t Ic, int d,
+                                   const int32_t *d_users, const int32_t *d_pos_slot, const int32_t *d_neg_slot, int64_t B,
+                                   float lr, float reg, double *d_loss)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_TRY(check_step_args(d_P, d_Qc, d_bc, U, Ic, d, d_users, d_pos_slot, d_neg_slot, B));
+    if (B == 0) {
+        if (d_loss) TF_HIP(hipMemsetAsync(d_loss, 0, 2 * sizeof(double), ctx->stream));
+        return TFREC_OK;
+    }
+    tfrec_marks_reset(ctx);
+    tfrec_mark(ctx, "start");
+    tfrec_batch_slot &sl = ctx->slots[2];
+    TF_TRY(slot_prepare(ctx, sl, ctx->stream, d_users, d_pos_slot, d_neg_slot, B, U, Ic));
+    tfrec_mark(ctx, "index");
+    return bpr_passes(ctx, sl, d_P, d_Qc, d_bc, U, d, lr, reg, d_loss, true);
+}
+
+extern "C" int tfrec_rows_sgd_apply(tfrec_ctx *ctx, float *d_Q, float *d_b, int64_t I, int d, const int32_t *d_ids,
+                                    const float *d_grad_rows, const float *d_grad_b, int64_t n, float lr)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_REQUIRE(d_Q && d_b && I > 0 && I < (1ll << 31) && d > 0, TFREC_EINVAL, "bad table");
+    TF_REQUIRE(n >= 0 && n < (1ll << 31), TFREC_EINVAL, "bad row count");
+    if (n == 0) return TFREC_OK;
+    TF_REQUIRE(d_ids && d_grad_rows && d_grad_b, TFREC_EINVAL, "null pointer");
+    RowCfg cfg;
+    TF_REQUIRE(pick_cfg(d, all_aligned16({d_Q, d_grad_rows}), &cfg), TFREC_EUNSUP, "factor size d=%d is not supported (max 256)", d);
+    const int CH = cfg.lpr > 32 ? cfg.lpr : 32, GPB = 256 / cfg.lpr;
+    const int64_t tiles = (n + CH - 1) / CH + 1;
+    const size_t rowf = (size_t)cfg.lpr * cfg.nch * cfg.vec;
+    const int end_bit = bits_for((uint64_t)I);
+    const size_t sort_bytes = tfrec_sort_temp_bytes((size_t)n, end_bit);
+    const size_t need = 4 * tf_align(4 * (size_t)n) + tf_align(sort_bytes) + tf_align(sizeof(float) * 2 * tiles * rowf) +
+                        tf_align(sizeof(float4) * 2 * tiles) + tf_align(4 * tiles) + 8192;
+    TF_TRY(tfrec_ws_require(ctx, ctx->ws_used + need));
+    uint32_t *keys_in = (uint32_t *)tfrec_ws_take(ctx, 4 * (size_t)n), *vals_in = (uint32_t *)tfrec_ws_take(ctx, 4 * (size_t)n);
+    uint32_t *keys = (uint32_t *)tfrec_ws_take(ctx, 4 * (size_t)n), *vals = (uint32_t *)tfrec_ws_take(ctx, 4 * (size_t)n);
+    void *sort_tmp = tfrec_ws_take(ctx, sort_bytes);
+    StepWs w{};
+    w.part_rows = (float *)tfrec_ws_take(ctx, sizeof(float) * 2 * tiles * rowf);
+    w.part_sc = (float4 *)tfrec_ws_take(ctx, sizeof(float4) * 2 * tiles);
+    w.tile_flags = (uint32_t *)tfrec_ws_take(ctx, 4 * tiles);
+    TF_REQUIRE(w.tile_flags != nullptr, TFREC_ENOMEM, "internal: workspace carve failed");
+    const int64_t n_tiles = (n + CH - 1) / CH;
+    const int blocks = (int)((n_tiles + GPB - 1) / GPB);
+    iota_keys_kernel<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(d_ids, n, (uint32_t)I, keys_in, vals_in, ctx->d_flags);
+    TF_HIP(hipGetLastError());
+    TF_TRY(tfrec_sort_pairs(sort_tmp, sort_bytes, keys_in, keys, vals_in, vals, (size_t)n, end_bit, ctx->stream));
+    RowsApplyParams a{d_Q, d_b, d_grad_rows, d_grad_b, d, d / cfg.vec, lr};
+    return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC>() -> int {
+        return run_pass(ctx, RowsApplyPol<LPR, NCH, VEC>{a}, w, keys, vals, 0, n, n_tiles, blocks, false, "apply_tile", "apply_fixup");
     });
 }
 

@@ -193,6 +193,20 @@ class Device:
         _lib.check(self.lib.tfrec_bpr_sgd_step_prepared(self.h, int(slot), _ptr(P), _ptr(Q), _ptr(b), U, I, d, float(lr), float(reg),
                                                         _ptr(loss)))
 
+    def bpr_grad_step(self, P, Qc, bc, users, pos_slot, neg_slot, lr, reg, loss=None):
+        """Sharded step, compute side: P updated in place, Qc/bc (fetched item rows) replaced by gradient sums."""
+        U, d = _shape(P)
+        Ic = _shape(Qc)[0]
+        B = _shape(users)[0]
+        _lib.check(self.lib.tfrec_bpr_grad_step(self.h, _ptr(P), _ptr(Qc), _ptr(bc), U, Ic, d, _ptr(users), _ptr(pos_slot),
+                                                _ptr(neg_slot), B, float(lr), float(reg), _ptr(loss)))
+
+    def rows_sgd_apply(self, Q, b, ids, grad_rows, grad_b, lr):
+        """Sharded step, owner side: Q[ids] -= lr * grad_rows (duplicates summed in order), b likewise."""
+        I, d = _shape(Q)
+        n = _shape(ids)[0]
+        _lib.check(self.lib.tfrec_rows_sgd_apply(self.h, _ptr(Q), _ptr(b), I, d, _ptr(ids), _ptr(grad_rows), _ptr(grad_b), n, float(lr)))
+
     def apr_adagrad_step(self, P, Q, b, accP, accQ, accb, dP, dQ, db, users, pos, neg, lr, reg, reg_adv, eps, loss=None):
         """Both session calls of model/APR.py:163-164.  ``loss``: optional device float64[3]."""
         U, d = _shape(P)
@@ -223,6 +237,19 @@ class Device:
         tp, ti = (train if train is not None else (None, None))
         _lib.check(self.lib.tfrec_score_topk(self.h, _ptr(P), _ptr(Q), _ptr(b), I, d, lo, hi, _ptr(eval_users), n, _ptr(tp), _ptr(ti),
                                              int(k), int(mode), _ptr(out_ids), _ptr(out_scores)))
+        return out_ids, out_scores
+
+    def score_topk_shard(self, P_rows, Q_shard, b_shard, item_id_lo, eval_users, k, train=None, mode=SCORE_F32,
+                         out_ids=None, out_scores=None):
+        """One item shard's top-k: P_rows[r] is the factor row of eval_users[r]; ids are global."""
+        n, d = _shape(P_rows)
+        ni = _shape(Q_shard)[0]
+        out_ids = out_ids if out_ids is not None else self.empty((n, k), np.int32)
+        out_scores = out_scores if out_scores is not None else self.empty((n, k), np.float32)
+        tp, ti = (train if train is not None else (None, None))
+        _lib.check(self.lib.tfrec_score_topk_shard(self.h, _ptr(P_rows), _ptr(Q_shard), _ptr(b_shard), ni, int(item_id_lo), d,
+                                                   _ptr(eval_users), n, _ptr(tp), _ptr(ti), int(k), int(mode), _ptr(out_ids),
+                                                   _ptr(out_scores)))
         return out_ids, out_scores
 
     def topk_merge(self, ids, scores, G, n, k, out_ids=None, out_scores=None):

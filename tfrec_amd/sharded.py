@@ -1,0 +1,228 @@
+"""Multi-GPU training and evaluation of the matrix-factorization path: one process per GPU over
+torch.distributed (backend "nccl" = RCCL over xGMI on a node; "gloo" on CPU for tests).
+
+The reference is a single process (run_model.py:14-16); nothing here translates reference code.
+The arithmetic is still that of model/BPR.py:36-48 and evaluator/evaluator.py:29-32.
+
+Layout
+  * user table P sharded by contiguous user ranges, item table Q / bias b by contiguous item
+    ranges; rank r owns users [r*Upr, (r+1)*Upr) and items [r*Ipr, (r+1)*Ipr).
+  * training: every triple is routed to the rank that owns its USER, so P rows never travel.  Per
+    step a rank (1) deduplicates the items its batch touches, (2) all-to-all: requests them from
+    their owners, (3) all-to-all: receives the rows, (4) runs the step on its P shard and the
+    fetched copies, which leaves one summed gradient per distinct item, (5) all-to-all: returns
+    those sums, (6) owners add the sums of all ranks in rank order and apply the SGD update.
+    Wire traffic per triple is at most two item rows each way, less after deduplication.
+  * evaluation: item-sharded.  The factor rows of a chunk of evaluated users are broadcast from
+    their owner, every rank takes the top-k over its own items (global ids), the lists are
+    all-gathered and merged under the total order (score desc, id asc) -- so the result is that
+    of an unsharded evaluation -- and the metric sums are all-reduced.
+
+All device arithmetic goes through a *backend* object.  The product backend is ``HipBackend``
+(the C ABI on this rank's GPU, torch CUDA tensors as buffers).  Tests inject a CPU backend to
+run the exchange logic under gloo without a GPU; this module never falls back by itself.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def _part(n, world):
+    per = (n + world - 1) // world
+    return per
+
+
+class HipBackend:
+    """Local compute through libtfrec_amd on this rank's GPU."""
+
+    def __init__(self, dev):
+        self.dev = dev
+
+    def bpr_grad_step(self, P, Qc, bc, users, pos_slot, neg_slot, lr, reg):
+        self.dev.bpr_grad_step(P, Qc, bc, users, pos_slot, neg_slot, lr, reg)
+
+    def rows_sgd_apply(self, Q, b, ids, grad_rows, grad_b, lr):
+        self.dev.rows_sgd_apply(Q, b, ids, grad_rows, grad_b, lr)
+
+    def score_topk_shard(self, P_rows, Q, b, item_lo, users, k, train, mode):
+        n = P_rows.shape[0]
+        ids = torch.empty((n, k), dtype=torch.int32, device=P_rows.device)
+        sc = torch.empty((n, k), dtype=torch.float32, device=P_rows.device)
+        self.dev.score_topk_shard(P_rows, Q, b, item_lo, users, k, train=train, mode=mode, out_ids=ids, out_scores=sc)
+        return ids, sc
+
+    def topk_merge(self, ids, scores, G, n, k):
+        oi = torch.empty((n, k), dtype=torch.int32, device=ids.device)
+        os_ = torch.empty((n, k), dtype=torch.float32, device=ids.device)
+        self.dev.topk_merge(ids, scores, G, n, k, out_ids=oi, out_scores=os_)
+        return oi, os_
+
+    def fill_masked(self, ids, users, k, train):
+        self.dev.topk_fill_masked(ids, users, k, train)
+
+    def metric_sums(self, ids, users, k, test):
+        sums = torch.empty(5 * k, dtype=torch.float64, device=ids.device)
+        self.dev.rank_metrics_sums(ids, users, k, test, sums=sums)
+        return sums
+
+    def uniform_rows(self, row_lo, row_hi, d, lo, hi, seed, device):
+        """Rows [row_lo, row_hi) of the table the counter-based generator would fill for ``seed``."""
+        t = torch.empty((row_hi - row_lo, d), dtype=torch.float32, device=device)
+        from . import _lib
+        _lib.check(self.dev.lib.tfrec_fill_uniform_at(self.dev.h, t.data_ptr(), t.numel(), float(lo), float(hi), int(seed),
+                                                      int(row_lo) * int(d)))
+        return t
+
+    def sync(self):
+        self.dev.synchronize()
+
+
+def make_device(local_rank):
+    """A Device whose stream is also torch's current stream on that GPU, so that torch ops (the
+    exchange plumbing) and library kernels are ordered without extra synchronisation."""
+    from .device import Device
+    torch.cuda.set_device(local_rank)
+    stream = torch.cuda.Stream(device=torch.device("cuda", local_rank))
+    torch.cuda.set_stream(stream)
+    dev = Device(local_rank, stream=stream.cuda_stream)
+    dev._torch_stream = stream          # keep the stream alive as long as the context
+    return dev
+
+
+class ShardedBprTrainer:
+    """BPR-MF with row-sharded tables.  ``step`` takes this rank's triples: global ids, every user
+    inside ``user_range``."""
+
+    def __init__(self, dev_or_backend, U, I, d, lr, reg, seed=2018, device=None, group=None):
+        self.backend = dev_or_backend if hasattr(dev_or_backend, "bpr_grad_step") else HipBackend(dev_or_backend)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.U, self.I, self.d, self.lr, self.reg = int(U), int(I), int(d), float(lr), float(reg)
+        self.upr, self.ipr = _part(self.U, self.world), _part(self.I, self.world)
+        self.user_range = (min(self.rank * self.upr, self.U), min((self.rank + 1) * self.upr, self.U))
+        self.item_range = (min(self.rank * self.ipr, self.I), min((self.rank + 1) * self.ipr, self.I))
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        self.device = device
+        nu, ni = self.user_range[1] - self.user_range[0], self.item_range[1] - self.item_range[0]
+        # model/base/MatrixFactorization.py:17-21; the stream of random numbers is that of the unsharded
+        # table, so the shards of any world size assemble into the same initial model
+        self.P = self._init_rows(self.U, self.user_range, seed * 2 + 1)
+        self.Q = self._init_rows(self.I, self.item_range, seed * 2 + 2)
+        self.b = torch.zeros(max(ni, 1), dtype=torch.float32, device=device)[:ni]
+        assert self.P.shape[0] == nu and self.Q.shape[0] == ni
+
+    def _init_rows(self, n_total, rng, seed):
+        return self.backend.uniform_rows(rng[0], rng[1], self.d, -0.05, 0.05, seed, self.device)
+
+    # ------------------------------------------------------------------------------------------
+    def _a2a(self, send, send_counts, recv_counts):
+        """all_to_all_single with per-rank row counts (lists of ints)."""
+        out = torch.empty((int(sum(recv_counts)),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        if self.world == 1:
+            out.copy_(send)
+            return out
+        dist.all_to_all_single(out, send.contiguous(), list(recv_counts), list(send_counts), group=self.group)
+        return out
+
+    def step(self, users, pos, neg):
+        """One global minibatch step; collective: every rank must call it (an empty batch is allowed)."""
+        dev, W = self.device, self.world
+        users = users.to(torch.int32)
+        items = torch.cat([pos, neg]).to(torch.int64)
+        # (1) distinct items of this rank's batch, ascending -> grouped by owner
+        uniq, inverse = torch.unique(items, sorted=True, return_inverse=True)
+        B = users.shape[0]
+        pos_slot = inverse[:B].to(torch.int32).contiguous()
+        neg_slot = inverse[B:].to(torch.int32).contiguous()
+        bounds = torch.arange(0, W + 1, device=dev, dtype=torch.int64) * self.ipr
+        cuts = torch.searchsorted(uniq, bounds)
+        send_counts = (cuts[1:] - cuts[:-1]).to(torch.int64)
+        # (2) how many ids each owner will be asked for
+        if W > 1:
+            recv_counts = torch.empty_like(send_counts)
+            dist.all_to_all_single(recv_counts, send_counts, group=self.group)
+        else:
+            recv_counts = send_counts.clone()
+        sc, rc = send_counts.tolist(), recv_counts.tolist()
+        want = self._a2a(uniq.to(torch.int32), sc, rc)                  # ids the others want from me (global)
+        local = (want.to(torch.int64) - self.item_range[0])
+        # (3) my rows for them: [row | bias]
+        payload = torch.cat([self.Q.index_select(0, local), self.b.index_select(0, local).unsqueeze(1)], dim=1)
+        got = self._a2a(payload, rc, sc)                                # rows of my distinct items, in uniq order
+        Qc = got[:, :self.d].contiguous()
+        bc = got[:, self.d].contiguous()
+        # (4) local step: P shard updated in place, Qc/bc turned into gradient sums
+        if B > 0:
+            self.backend.bpr_grad_step(self.P, Qc, bc, (users - self.user_range[0]).contiguous(), pos_slot, neg_slot, self.lr, self.reg)
+        else:
+            Qc.zero_(); bc.zero_()
+        # (5) gradient sums back to the owners, (6) owners reduce in rank order and apply
+        grads = self._a2a(torch.cat([Qc, bc.unsqueeze(1)], dim=1), sc, rc)
+        if grads.shape[0] > 0:
+            self.backend.rows_sgd_apply(self.Q, self.b, local.to(torch.int32).contiguous(), grads[:, :self.d].contiguous(),
+                                        grads[:, self.d].contiguous(), self.lr)
+
+    def gather_full(self):
+        """(P, Q, b) assembled on every rank (testing / checkpointing)."""
+        def cat(x, n):
+            if self.world == 1:
+                return x.clone()
+            per = _part(n, self.world)
+            pad = torch.zeros((per,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+            pad[: x.shape[0]] = x
+            outs = [torch.empty_like(pad) for _ in range(self.world)]
+            dist.all_gather(outs, pad, group=self.group)
+            return torch.cat(outs)[:n]
+        return cat(self.P, self.U), cat(self.Q, self.I), cat(self.b, self.I)
+
+
+class ShardedEvaluator:
+    """Item-sharded full-rank evaluation.  ``train`` / ``test`` are (indptr int64, indices int32)
+    tensors over ALL users on this rank's device (replicated); ``test_users`` the sorted global ids
+    of the users to evaluate (replicated)."""
+
+    def __init__(self, dev_or_backend, trainer, train, test, test_users, top_k=50, mode=0, chunk_users=1 << 18):
+        self.backend = dev_or_backend if hasattr(dev_or_backend, "score_topk_shard") else HipBackend(dev_or_backend)
+        self.t = trainer
+        self.train, self.test = train, test
+        self.test_users = test_users.to(torch.int32)
+        self.k, self.mode, self.chunk = int(top_k), int(mode), int(chunk_users)
+
+    def _gather_lists(self, x):
+        """[n, k] per rank -> [world, n, k] on every rank (800 bytes per user and rank at k=100)."""
+        t = self.t
+        if t.world == 1:
+            return x.unsqueeze(0)
+        outs = [torch.empty_like(x) for _ in range(t.world)]
+        dist.all_gather(outs, x.contiguous(), group=t.group)
+        return torch.stack(outs)
+
+    def evaluate(self):
+        """float32 [5, k] on every rank: Precision, Recall, MAP, NDCG, MRR @1..k."""
+        t, k, W = self.t, self.k, self.t.world
+        dev = t.device
+        sums = torch.zeros(5 * k, dtype=torch.float64, device=dev)
+        owners = torch.div(self.test_users.to(torch.int64), t.upr, rounding_mode="floor")
+        for o in range(W):
+            users_o = self.test_users[owners == o]
+            for s in range(0, users_o.shape[0], self.chunk):
+                eu = users_o[s:s + self.chunk].contiguous()
+                n = eu.shape[0]
+                if t.rank == o:
+                    rows = t.P.index_select(0, eu.to(torch.int64) - t.user_range[0]).contiguous()
+                else:
+                    rows = torch.empty((n, t.d), dtype=torch.float32, device=dev)
+                if W > 1:
+                    dist.broadcast(rows, src=o, group=t.group)
+                ids, sc = self.backend.score_topk_shard(rows, t.Q, t.b, t.item_range[0], eu, k, self.train, self.mode)
+                all_ids, all_sc = self._gather_lists(ids), self._gather_lists(sc)
+                if t.rank == o:        # the owner of the users merges, fills the masked tail and scores
+                    mi, _ = self.backend.topk_merge(all_ids.contiguous(), all_sc.contiguous(), W, n, k)
+                    if self.train is not None:
+                        self.backend.fill_masked(mi, eu, k, self.train)
+                    sums += self.backend.metric_sums(mi, eu, k, self.test)
+        if W > 1:
+            dist.all_reduce(sums, group=t.group)
+        return (sums / float(self.test_users.shape[0])).to(torch.float32).reshape(5, k)
