@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--topk", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU code path even on one GPU (testing)")
     ap.add_argument("--extras", action="store_true", help="also time the reference batch size (512 triples per step)")
     args = ap.parse_args()
 
@@ -113,7 +114,7 @@ def main():
 
     with torch.cuda.stream(stream):
         dev = Device(local_rank, stream=stream.cuda_stream)
-        if world == 1:
+        if world == 1 and not args.force_sharded:
             P = (torch.rand(U, d, device=cuda, generator=gen) - 0.5) * 0.1     # U(-0.05, 0.05)
             Q = (torch.rand(I, d, device=cuda, generator=gen) - 0.5) * 0.1
             b = torch.zeros(I, device=cuda)
@@ -186,7 +187,7 @@ def main():
                        "parallelism": "single GPU" if world == 1 else "tables row-sharded over %d GPUs, all-to-all per step" % world},
         }
 
-        if rank == 0 and world == 1:
+        if rank == 0 and world == 1 and not args.force_sharded:
             # ---- roofline of the step's kernels: HIP events recorded by the library on its own stream
             # (un-pipelined steps, so that the index phase is timed on the same stream as the row passes)
             dev.set_profiling(True)

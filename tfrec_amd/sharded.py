@@ -94,7 +94,7 @@ class ShardedBprTrainer:
     inside ``user_range``."""
 
     def __init__(self, dev_or_backend, U, I, d, lr, reg, seed=2018, device=None, group=None):
-        self.backend = dev_or_backend if hasattr(dev_or_backend, "bpr_grad_step") else HipBackend(dev_or_backend)
+        self.backend = dev_or_backend if hasattr(dev_or_backend, "uniform_rows") else HipBackend(dev_or_backend)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -184,7 +184,7 @@ class ShardedEvaluator:
     of the users to evaluate (replicated)."""
 
     def __init__(self, dev_or_backend, trainer, train, test, test_users, top_k=50, mode=0, chunk_users=1 << 18):
-        self.backend = dev_or_backend if hasattr(dev_or_backend, "score_topk_shard") else HipBackend(dev_or_backend)
+        self.backend = dev_or_backend if hasattr(dev_or_backend, "metric_sums") else HipBackend(dev_or_backend)
         self.t = trainer
         self.train, self.test = train, test
         self.test_users = test_users.to(torch.int32)
