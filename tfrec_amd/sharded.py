@@ -112,6 +112,7 @@ class ShardedBprTrainer:
         self.Q = self._init_rows(self.I, self.item_range, seed * 2 + 2)
         self.b = torch.zeros(max(ni, 1), dtype=torch.float32, device=device)[:ni]
         assert self.P.shape[0] == nu and self.Q.shape[0] == ni
+        self._mark = None
 
     def _init_rows(self, n_total, rng, seed):
         return self.backend.uniform_rows(rng[0], rng[1], self.d, -0.05, 0.05, seed, self.device)
@@ -130,15 +131,22 @@ class ShardedBprTrainer:
         """One global minibatch step; collective: every rank must call it (an empty batch is allowed)."""
         dev, W = self.device, self.world
         users = users.to(torch.int32)
-        items = torch.cat([pos, neg]).to(torch.int64)
-        # (1) distinct items of this rank's batch, ascending -> grouped by owner
-        uniq, inverse = torch.unique(items, sorted=True, return_inverse=True)
         B = users.shape[0]
-        pos_slot = inverse[:B].to(torch.int32).contiguous()
-        neg_slot = inverse[B:].to(torch.int32).contiguous()
-        bounds = torch.arange(0, W + 1, device=dev, dtype=torch.int64) * self.ipr
-        cuts = torch.searchsorted(uniq, bounds)
-        send_counts = (cuts[1:] - cuts[:-1]).to(torch.int64)
+        items = torch.cat([pos, neg]).to(torch.int64)
+        # (1) distinct items of this rank's batch, ascending (hence grouped by owner), without a sort:
+        #     presence marks over the item range, a prefix sum for the slots, a compaction for the ids
+        if self._mark is None:
+            self._mark = torch.zeros(self.I, dtype=torch.int32, device=dev)
+        mark = self._mark
+        mark.zero_()
+        mark.index_fill_(0, items, 1)
+        rank = torch.cumsum(mark, 0, dtype=torch.int32)
+        uniq = torch.nonzero(mark).squeeze(1)
+        slots = rank.index_select(0, items) - 1
+        pos_slot, neg_slot = slots[:B].contiguous(), slots[B:].contiguous()
+        ends = torch.clamp(torch.arange(1, W + 1, device=dev, dtype=torch.int64) * self.ipr, max=self.I) - 1
+        upto = rank.index_select(0, ends).to(torch.int64)                 # distinct items below each owner's upper bound
+        send_counts = upto - torch.cat([upto.new_zeros(1), upto[:-1]])
         # (2) how many ids each owner will be asked for
         if W > 1:
             recv_counts = torch.empty_like(send_counts)
