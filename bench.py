@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--topk", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
+    ap.add_argument("--prep-batches", type=int, default=1, help="batches sorted per index preparation (single GPU)")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU code path even on one GPU (testing)")
     ap.add_argument("--extras", action="store_true", help="also time the reference batch size (512 triples per step)")
     args = ap.parse_args()
@@ -129,13 +130,23 @@ def main():
 
             # the index work of batch s+1 is enqueued on the library's auxiliary stream before the row
             # passes of batch s, so the two overlap; every step still does all of its own work
+            # (K batches are sorted per preparation, so the fixed costs of the index phase are paid once per K steps)
+            K = args.prep_batches
+            assert n_batches % K == 0
+
+            def group(g):
+                o = ((g * K) % n_batches) * B
+                return users[o:o + K * B], pos[o:o + K * B], neg[o:o + K * B]
+
             state = {"next": 0}
-            dev.prepare_batch(0, U, I, *batch(0))
+            dev.prepare_batches(0, U, I, *group(0), K)
 
             def step(s):
                 k = state["next"]
-                dev.prepare_batch((k + 1) & 1, U, I, *batch(k + 1))
-                dev.bpr_sgd_step_prepared(k & 1, P, Q, b, lr, reg)
+                g, r = divmod(k, K)
+                if r == 0:
+                    dev.prepare_batches((g + 1) & 1, U, I, *group(g + 1), K)
+                dev.bpr_sgd_step_prepared(g & 1, P, Q, b, lr, reg)
                 state["next"] = k + 1
             trainer = None
         else:

@@ -115,6 +115,11 @@ int tfrec_bpr_sgd_step(tfrec_ctx *ctx, float *d_P, float *d_Q, float *d_b,
  * tfrec_bpr_sgd_step on the same batch. */
 int tfrec_batch_prepare(tfrec_ctx *ctx, int slot, int64_t U, int64_t I,
                         const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg, int64_t B);
+/* K consecutive batches (index arrays of K*B triples) sorted in ONE pass: the fixed costs of the
+ * index phase are paid once per K steps.  The next K calls of tfrec_bpr_sgd_step_prepared on that
+ * slot consume the batches in order. */
+int tfrec_batch_prepare_many(tfrec_ctx *ctx, int slot, int64_t U, int64_t I,
+                             const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg, int64_t B, int K);
 int tfrec_bpr_sgd_step_prepared(tfrec_ctx *ctx, int slot, float *d_P, float *d_Q, float *d_b,
                                 int64_t U, int64_t I, int d, float lr, float reg, double *d_loss);
 

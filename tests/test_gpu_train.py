@@ -54,6 +54,7 @@ def zipf_ids(rng, n, size, a=1.0):
     (300, 200, 10, 777, "uniform"),         # d not a multiple of 4: scalar row path
     (300, 200, 256, 600, "uniform"),
     (1, 2, 8, 300, "uniform"),
+    (3, 2, 64, 200000, "uniform"),          # one row spans thousands of tiles: pre-summed workgroup partials
 ])
 def test_bpr_step_vs_oracle(dev, oracle, U, I, d, B, kind):
     rng = np.random.default_rng(U * 7 + B)
@@ -117,6 +118,17 @@ def test_prepared_steps_equal_plain_steps(dev):
     assert loss.numpy()[0] > 0
     with pytest.raises(ValueError):
         dev.bpr_sgd_step_prepared(0, *c, 0.01, 0.05)        # the slot was consumed
+    # several batches sorted in one pass, consumed one per step
+    e = [dev.array(x) for x in (P, Q, b)]
+    host = [[x.numpy() for x in bt] for bt in batches]
+    for g0 in range(0, steps, 3):
+        grp = [dev.array(np.concatenate([host[s][c] for s in range(g0, g0 + 3)])) for c in range(3)]
+        dev.prepare_batches((g0 // 3) & 1, U, I, *grp, 3)
+        for s in range(3):
+            dev.bpr_sgd_step_prepared((g0 // 3) & 1, *e, 0.01, 0.05)
+    dev.synchronize()
+    for x, y in zip(a, e):
+        assert np.array_equal(x.numpy(), y.numpy())
 
 
 def test_bpr_empty_batch_and_bad_index(dev):

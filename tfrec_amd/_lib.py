@@ -43,6 +43,7 @@ SIGNATURES = {
     "tfrec_mf_predict": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _i64, _p]),
     "tfrec_bpr_sgd_step": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _i64, _f, _f, _p]),
     "tfrec_batch_prepare": (_int, [_p, _int, _i64, _i64, _p, _p, _p, _i64]),
+    "tfrec_batch_prepare_many": (_int, [_p, _int, _i64, _i64, _p, _p, _p, _i64, _int]),
     "tfrec_bpr_sgd_step_prepared": (_int, [_p, _int, _p, _p, _p, _i64, _i64, _int, _f, _f, _p]),
     "tfrec_bpr_grad_step": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _i64, _f, _f, _p]),
     "tfrec_rows_sgd_apply": (_int, [_p, _p, _p, _i64, _int, _p, _p, _p, _i64, _f]),

@@ -46,6 +46,8 @@ struct tfrec_batch_slot {
     char *mem = nullptr;
     size_t bytes = 0;
     int64_t B = -1, U = 0, I = 0;            // B < 0: nothing prepared
+    int K = 1, next_k = 0;                   // batches sorted together / next one to consume
+    uint32_t kmask = 0xffffffffu;            // key bits below the batch number
     uint32_t *keys = nullptr, *vals = nullptr;   // [3B] sorted: user side [0,B), item side [B,3B)
     uint2 *pair = nullptr;
     hipEvent_t ready = nullptr;              // recorded on the auxiliary stream after preparation

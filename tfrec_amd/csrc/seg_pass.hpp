@@ -101,13 +101,18 @@ template <class Pol>
 __global__ __launch_bounds__(256) void seg_tile_kernel(Pol pol, const uint32_t *__restrict__ keys,
                                                        const uint32_t *__restrict__ vals, int64_t base, int64_t n,
                                                        float *__restrict__ part_rows, float4 *__restrict__ part_sc,
-                                                       uint32_t *__restrict__ tile_flags, double *__restrict__ loss_part)
+                                                       uint32_t *__restrict__ tile_flags, int64_t blk_slot0,
+                                                       double *__restrict__ loss_part)
 {
     constexpr int LPR = Pol::LPR, NCH = Pol::NCH, VEC = Pol::VEC;
     using RowT = typename Pol::RowT;
     using G = TileGeom<LPR>;
     constexpr int CH = G::CH, EPL = G::EPL, GPB = G::GPB;
+    constexpr int ROWF = LPR * NCH * VEC;
     __shared__ uint4 ent[GPB][CH];
+    __shared__ __align__(16) float bred[GPB][ROWF];
+    __shared__ float4 bsc[GPB];
+    __shared__ uint32_t bthrough[GPB];
 
     const int gl = threadIdx.x % LPR;
     const int g = threadIdx.x / LPR;
@@ -127,17 +132,18 @@ __global__ __launch_bounds__(256) void seg_tile_kernel(Pol pol, const uint32_t *
 
     typename Pol::Loss loss;
     loss.clear();
+    Acc<RowT> acc;
+    acc.clear();
+    uint32_t lead_kind = LEAD_NONE;
     if (cnt > 0) {
         const uint32_t key_prev = a > 0 ? keys[base + a - 1] : NOKEY;
         const uint32_t key_next = a + cnt < n ? keys[base + a + cnt] : NOKEY;
-        uint32_t lead_kind = LEAD_NONE, tail = 0;
+        uint32_t tail = 0;
 
         uint4 en = ent[g][0];
         typename Pol::Occ nx = pol.load_occ(en, gl);
         typename Pol::Seg nseg = pol.load_seg(en.x, gl);
         typename Pol::Seg seg = nseg;
-        Acc<RowT> acc;
-        acc.clear();
         bool lead_open = (en.x == key_prev);
         uint32_t cur_key = en.x;
 
@@ -177,6 +183,32 @@ __global__ __launch_bounds__(256) void seg_tile_kernel(Pol pol, const uint32_t *
         }
         if (gl == 0) tile_flags[w] = lead_kind | tail;
     }
+    // A hot row fills whole workgroups with tiles that lie entirely inside its segment.  Such a
+    // workgroup also leaves ONE pre-summed partial (its tiles added in tile order), so the chain the
+    // fix-up kernel has to add for that row is GPB times shorter.
+    const bool through = lead_kind == LEAD_THROUGH;
+    if (gl == 0) bthrough[g] = through ? 1u : 0u;
+    if (through) {
+        acc.v.store(&bred[g][0], gl, LPR * NCH);
+        if (gl == 0) bsc[g] = make_float4(acc.s0, acc.s1, __int_as_float(acc.cnt), 0.f);
+    }
+    __syncthreads();
+    if (g == 0) {
+        bool all = true;
+        for (int i = 0; i < GPB; ++i) all = all && bthrough[i] != 0u;
+        if (all) {
+            Acc<RowT> tot;
+            tot.clear();
+            for (int i = 0; i < GPB; ++i) {
+                Acc<RowT> pi;
+                pi.v = RowT::load(&bred[i][0], gl, LPR * NCH);
+                const float4 sc4 = bsc[i];
+                pi.s0 = sc4.x; pi.s1 = sc4.y; pi.cnt = __float_as_int(sc4.z);
+                tot.add(pi);
+            }
+            part_store<RowT, LPR, NCH, VEC>(part_rows, part_sc, blk_slot0 + blockIdx.x, tot, gl);
+        }
+    }
     if constexpr (Pol::Loss::N > 0) block_loss_store(loss, loss_part);
 }
 
@@ -184,7 +216,7 @@ __global__ __launch_bounds__(256) void seg_tile_kernel(Pol pol, const uint32_t *
 template <class Pol>
 __global__ __launch_bounds__(256) void seg_fixup_kernel(Pol pol, const uint32_t *__restrict__ keys, int64_t base, int64_t n,
                                                         const float *__restrict__ part_rows, const float4 *__restrict__ part_sc,
-                                                        const uint32_t *__restrict__ tile_flags, int64_t n_tiles)
+                                                        const uint32_t *__restrict__ tile_flags, int64_t n_tiles, int64_t blk_slot0)
 {
     constexpr int LPR = Pol::LPR, NCH = Pol::NCH, VEC = Pol::VEC;
     using RowT = typename Pol::RowT;
@@ -264,21 +296,34 @@ __global__ __launch_bounds__(256) void seg_fixup_kernel(Pol pol, const uint32_t 
             if (fe != INT32_MAX) { L = fe + 1; break; }
         }
         if (wl + L >= n_tiles) L = (int)(n_tiles - 1 - wl);
-        // group g sums a contiguous share of the lead partials wl+1 .. wl+L in tile order, four loads in flight
-        const int per = (L + GPB - 1) / GPB;
+        // The chain is the lead partials of tiles wl+1 .. wl+L; all but the last lie wholly inside the row's
+        // segment.  Workgroups made only of such tiles were pre-summed by the tile kernel, so the chain
+        // becomes head tiles, workgroup partials [a0/GPB, a1/GPB), tail tiles.
+        // Group g sums a contiguous share of those items in order, four loads in flight.
+        const int64_t t_first = wl + 1, t_last = wl + L;                      // inclusive
+        int64_t a0 = (t_first + GPB - 1) / GPB * GPB, a1 = t_last / GPB * GPB;   // tiles [a0, a1) are whole workgroups
+        if (a1 < a0) { a0 = t_last + 1; a1 = a0; }
+        const int nh = (int)(a0 - t_first), nb = (int)((a1 - a0) / GPB), nt = (int)(t_last + 1 - a1);
+        const int n_items = nh + nb + nt;
+        auto slot_of = [&](int idx) -> int64_t {
+            if (idx < nh) return 2 * (t_first + idx);
+            if (idx < nh + nb) return blk_slot0 + a0 / GPB + (idx - nh);
+            return 2 * (a1 + (idx - nh - nb));
+        };
+        const int per = (n_items + GPB - 1) / GPB;
         Acc<RowT> part;
         part.clear();
         {
-            const int lo = g * per, hi = (g + 1) * per < L ? (g + 1) * per : L;
+            const int lo = g * per, hi = (g + 1) * per < n_items ? (g + 1) * per : n_items;
             int t = lo;
             for (; t + 4 <= hi; t += 4) {
-                Acc<RowT> q0 = part_load<RowT, LPR, NCH, VEC>(part_rows, part_sc, 2 * (wl + 1 + t), gl);
-                Acc<RowT> q1 = part_load<RowT, LPR, NCH, VEC>(part_rows, part_sc, 2 * (wl + 2 + t), gl);
-                Acc<RowT> q2 = part_load<RowT, LPR, NCH, VEC>(part_rows, part_sc, 2 * (wl + 3 + t), gl);
-                Acc<RowT> q3 = part_load<RowT, LPR, NCH, VEC>(part_rows, part_sc, 2 * (wl + 4 + t), gl);
+                Acc<RowT> q0 = part_load<RowT, LPR, NCH, VEC>(part_rows, part_sc, slot_of(t), gl);
+                Acc<RowT> q1 = part_load<RowT, LPR, NCH, VEC>(part_rows, part_sc, slot_of(t + 1), gl);
+                Acc<RowT> q2 = part_load<RowT, LPR, NCH, VEC>(part_rows, part_sc, slot_of(t + 2), gl);
+                Acc<RowT> q3 = part_load<RowT, LPR, NCH, VEC>(part_rows, part_sc, slot_of(t + 3), gl);
                 part.add(q0); part.add(q1); part.add(q2); part.add(q3);
             }
-            for (; t < hi; ++t) part.add(part_load<RowT, LPR, NCH, VEC>(part_rows, part_sc, 2 * (wl + 1 + t), gl));
+            for (; t < hi; ++t) part.add(part_load<RowT, LPR, NCH, VEC>(part_rows, part_sc, slot_of(t), gl));
         }
         part.v.store(&red_rows[g][0], gl, LPR * NCH);
         if (gl == 0) red_sc[g] = make_float4(part.s0, part.s1, __int_as_float(part.cnt), 0.f);

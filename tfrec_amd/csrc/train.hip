@@ -26,20 +26,23 @@ __device__ __forceinline__ uint32_t clamp_index(int32_t v, uint32_t n, bool *bad
     return (uint32_t)v;
 }
 
+// n = K*B triples of K consecutive batches; batch number k = t / B goes above bit `kb` of every key, so
+// one sort groups by (batch, side, row); occurrence ids are local to the batch
 __global__ __launch_bounds__(256) void build_keys_kernel(const int32_t *__restrict__ users, const int32_t *__restrict__ pos,
-                                                         const int32_t *__restrict__ neg, int64_t B, uint32_t U, uint32_t I,
-                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                         const int32_t *__restrict__ neg, int64_t n, int64_t B, int kb, uint32_t U,
+                                                         uint32_t I, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
                                                          uint2 *__restrict__ pair, uint32_t *__restrict__ flags)
 {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= B) return;
+    if (t >= n) return;
     bool bad = false;
     const uint32_t u = clamp_index(users[t], U, &bad), i = clamp_index(pos[t], I, &bad), j = clamp_index(neg[t], I, &bad);
     if (bad) atomicOr(flags, TFREC_FLAG_BAD_INDEX);
-    keys[t] = u;
-    vals[t] = (uint32_t)t;
-    reinterpret_cast<uint2 *>(keys + B)[t] = make_uint2(U + i, U + j);
-    reinterpret_cast<uint2 *>(vals + B)[t] = make_uint2((uint32_t)(2 * t), (uint32_t)(2 * t + 1));
+    const uint32_t k = (uint32_t)(t / B), tau = (uint32_t)(t - (int64_t)k * B), hi = k << kb;
+    keys[t] = hi | u;
+    vals[t] = tau;
+    reinterpret_cast<uint2 *>(keys + n)[t] = make_uint2(hi | (U + i), hi | (U + j));
+    reinterpret_cast<uint2 *>(vals + n)[t] = make_uint2(2 * tau, 2 * tau + 1);
     pair[t] = make_uint2(i, j);
 }
 
@@ -55,6 +58,7 @@ struct BprParams {
     uint32_t U;
     int d, nchunk;
     float lr, reg;
+    uint32_t kmask;      // sorted keys carry a batch number above these bits when several batches were sorted together
 };
 
 template <int LPR_, int NCH_, int VEC_, bool LOSS>
@@ -74,7 +78,7 @@ struct BprUserPol {
     __device__ __forceinline__ Occ load_occ(uint4 en, int gl) const
     {
         Occ o;
-        o.p = RowT::load(a.P + (size_t)en.x * a.d, gl, a.nchunk);
+        o.p = RowT::load(a.P + (size_t)(en.x & a.kmask) * a.d, gl, a.nchunk);
         o.qi = RowT::load(a.Q + (size_t)en.z * a.d, gl, a.nchunk);
         o.qj = RowT::load(a.Q + (size_t)en.w * a.d, gl, a.nchunk);
         o.bi = a.b[en.z];
@@ -104,7 +108,7 @@ struct BprUserPol {
     }
     __device__ __forceinline__ void apply(uint32_t key, const Seg *seg, const Acc<RowT> &acc, int gl) const
     {
-        float *row = a.P + (size_t)key * a.d;
+        float *row = a.P + (size_t)(key & a.kmask) * a.d;
         const RowT p = seg ? seg->p : RowT::load(row, gl, a.nchunk);
         const float nreg = (float)acc.cnt * a.reg, lr = a.lr;
         const RowT out = p.map2(acc.v, [=](float pv, float av) { return fmaf(-lr, fmaf(nreg, pv, -av), pv); });
@@ -135,7 +139,7 @@ struct BprItemPol {
     }
     __device__ __forceinline__ Seg load_seg(uint32_t key, int gl) const
     {
-        const uint32_t it = key - a.U;
+        const uint32_t it = (key & a.kmask) - a.U;
         return Seg{RowT::load(a.Q + (size_t)it * a.d, gl, a.nchunk), a.b[it]};
     }
     __device__ __forceinline__ void compute(Seg &, const Occ &o, uint4 en, Acc<RowT> &acc, Loss &, int) const
@@ -147,7 +151,7 @@ struct BprItemPol {
     }
     __device__ __forceinline__ void apply(uint32_t key, const Seg *seg, const Acc<RowT> &acc, int gl) const
     {
-        const uint32_t it = key - a.U;
+        const uint32_t it = (key & a.kmask) - a.U;
         float *row = a.Q + (size_t)it * a.d;
         const RowT q = seg ? seg->q : RowT::load(row, gl, a.nchunk);
         const float bk = seg ? seg->bk : a.b[it];
@@ -548,17 +552,22 @@ static int bits_for(uint64_t n)   // bits needed to represent values < n
 // The sorted index arrays of a batch live in a context-owned slot (not in the per-call
 // workspace) so that a batch can be prepared on the auxiliary stream while the previous step
 // still runs.
-static size_t slot_bytes(int64_t B, size_t *sort_bytes)
+static size_t slot_bytes(int64_t n, size_t *sort_bytes)
 {
-    *sort_bytes = tfrec_sort_temp_bytes((size_t)3 * B, 32);
-    return 4 * tf_align(12 * (size_t)B) + tf_align(8 * (size_t)B) + tf_align(*sort_bytes) + 4096;
+    *sort_bytes = tfrec_sort_temp_bytes((size_t)3 * n, 32);
+    return 4 * tf_align(12 * (size_t)n) + tf_align(8 * (size_t)n) + tf_align(*sort_bytes) + 4096;
 }
 
+// Sorts K consecutive batches of B triples (K*B index triples) into slot `sl`.
 static int slot_prepare(tfrec_ctx *ctx, tfrec_batch_slot &sl, hipStream_t stream, const int32_t *users, const int32_t *pos,
-                        const int32_t *neg, int64_t B, int64_t U, int64_t I)
+                        const int32_t *neg, int64_t B, int64_t U, int64_t I, int K = 1)
 {
+    const int64_t n = B * K;
+    const int kb = bits_for((uint64_t)U + (uint64_t)I);
+    const int total_bits = K > 1 ? kb + bits_for((uint64_t)K) : kb;
+    TF_REQUIRE(total_bits <= 32 && n < (1ll << 30), TFREC_EUNSUP, "%d batches of %lld triples do not fit the 32-bit sort keys", K, (long long)B);
     size_t sort_bytes = 0;
-    const size_t need = slot_bytes(B, &sort_bytes);
+    const size_t need = slot_bytes(n, &sort_bytes);
     if (need > sl.bytes) {
         // growing: nothing may still be reading the old block
         TF_HIP(hipStreamSynchronize(ctx->stream));
@@ -571,17 +580,17 @@ static int slot_prepare(tfrec_ctx *ctx, tfrec_batch_slot &sl, hipStream_t stream
     }
     char *p = sl.mem;
     auto take = [&](size_t bytes) { char *r = p; p += tf_align(bytes); return r; };
-    uint32_t *keys_in = (uint32_t *)take(12 * (size_t)B), *vals_in = (uint32_t *)take(12 * (size_t)B);
-    sl.keys = (uint32_t *)take(12 * (size_t)B);
-    sl.vals = (uint32_t *)take(12 * (size_t)B);
-    sl.pair = (uint2 *)take(8 * (size_t)B);
+    uint32_t *keys_in = (uint32_t *)take(12 * (size_t)n), *vals_in = (uint32_t *)take(12 * (size_t)n);
+    sl.keys = (uint32_t *)take(12 * (size_t)n);
+    sl.vals = (uint32_t *)take(12 * (size_t)n);
+    sl.pair = (uint2 *)take(8 * (size_t)n);
     void *sort_tmp = take(sort_bytes);
-    build_keys_kernel<<<(int)((B + 255) / 256), 256, 0, stream>>>(users, pos, neg, B, (uint32_t)U, (uint32_t)I, keys_in, vals_in,
-                                                                 sl.pair, ctx->d_flags);
+    build_keys_kernel<<<(int)((n + 255) / 256), 256, 0, stream>>>(users, pos, neg, n, B, kb, (uint32_t)U, (uint32_t)I, keys_in,
+                                                                 vals_in, sl.pair, ctx->d_flags);
     TF_HIP(hipGetLastError());
-    TF_TRY(tfrec_sort_pairs(sort_tmp, sort_bytes, keys_in, sl.keys, vals_in, sl.vals, (size_t)3 * B,
-                            bits_for((uint64_t)U + (uint64_t)I), stream));
-    sl.B = B; sl.U = U; sl.I = I;
+    TF_TRY(tfrec_sort_pairs(sort_tmp, sort_bytes, keys_in, sl.keys, vals_in, sl.vals, (size_t)3 * n, total_bits, stream));
+    sl.B = B; sl.U = U; sl.I = I; sl.K = K; sl.next_k = 0;
+    sl.kmask = kb >= 32 ? 0xffffffffu : ((1u << kb) - 1u);
     return TFREC_OK;
 }
 
@@ -589,6 +598,7 @@ struct StepWs {
     float *stage, *sbuf, *part_rows;
     float4 *part_sc;
     uint32_t *tile_flags;
+    int64_t blk_slot0;       // partial-record slot of workgroup 0's pre-summed partial
     double *loss_part, *scalars;
     int64_t n_tiles_u, n_tiles_i;
     int blocks_u, blocks_i;
@@ -602,8 +612,9 @@ static size_t step_ws_bytes(int64_t B, int d, const RowCfg &c)
     size_t s = 0;
     s += tf_align(sizeof(float) * (size_t)B * d);          // stage
     s += tf_align(sizeof(float) * B);                      // sbuf
-    s += tf_align(sizeof(float) * 2 * tiles * rowf);       // partial rows
-    s += tf_align(sizeof(float4) * 2 * tiles);
+    const int64_t slots = 2 * tiles + tiles / (256 / c.lpr) + 2;   // two per tile + one per workgroup
+    s += tf_align(sizeof(float) * slots * rowf);           // partial rows
+    s += tf_align(sizeof(float4) * slots);
     s += tf_align(sizeof(uint32_t) * tiles);
     s += tf_align(sizeof(double) * 4 * (tiles + 8));       // loss partials (<= one per block)
     s += tf_align(sizeof(double) * 16);
@@ -633,9 +644,11 @@ static int step_ws_carve(tfrec_ctx *ctx, int64_t B, int d, const RowCfg &c, Step
     const size_t rowf = (size_t)c.lpr * c.nch * c.vec;
     w->stage = (float *)tfrec_ws_take(ctx, sizeof(float) * (size_t)B * d);
     w->sbuf = (float *)tfrec_ws_take(ctx, sizeof(float) * B);
-    w->part_rows = (float *)tfrec_ws_take(ctx, sizeof(float) * 2 * tiles * rowf);
-    w->part_sc = (float4 *)tfrec_ws_take(ctx, sizeof(float4) * 2 * tiles);
+    const int64_t slots = 2 * tiles + tiles / GPB + 2;
+    w->part_rows = (float *)tfrec_ws_take(ctx, sizeof(float) * slots * rowf);
+    w->part_sc = (float4 *)tfrec_ws_take(ctx, sizeof(float4) * slots);
     w->tile_flags = (uint32_t *)tfrec_ws_take(ctx, sizeof(uint32_t) * tiles);
+    w->blk_slot0 = 2 * tiles;
     w->loss_part = (double *)tfrec_ws_take(ctx, sizeof(double) * 4 * (tiles + 8));
     w->scalars = (double *)tfrec_ws_take(ctx, sizeof(double) * 16);
     TF_REQUIRE(w->scalars != nullptr, TFREC_ENOMEM, "internal: workspace carve failed");
@@ -669,11 +682,11 @@ static int run_pass(tfrec_ctx *ctx, const Pol &pol, const StepWs &w, const uint3
                     int64_t n, int64_t n_tiles, int blocks, bool with_loss_part, const char *tile_name, const char *fix_name)
 {
     if (n <= 0) return TFREC_OK;
-    seg_tile_kernel<Pol><<<blocks, 256, 0, ctx->stream>>>(pol, keys, vals, base, n, w.part_rows, w.part_sc, w.tile_flags,
+    seg_tile_kernel<Pol><<<blocks, 256, 0, ctx->stream>>>(pol, keys, vals, base, n, w.part_rows, w.part_sc, w.tile_flags, w.blk_slot0,
                                                          with_loss_part ? w.loss_part : nullptr);
     TF_HIP(hipGetLastError());
     tfrec_mark(ctx, tile_name);
-    seg_fixup_kernel<Pol><<<blocks, 256, 0, ctx->stream>>>(pol, keys, base, n, w.part_rows, w.part_sc, w.tile_flags, n_tiles);
+    seg_fixup_kernel<Pol><<<blocks, 256, 0, ctx->stream>>>(pol, keys, base, n, w.part_rows, w.part_sc, w.tile_flags, n_tiles, w.blk_slot0);
     TF_HIP(hipGetLastError());
     tfrec_mark(ctx, fix_name);
     return TFREC_OK;
@@ -684,26 +697,28 @@ static int bpr_passes(tfrec_ctx *ctx, const tfrec_batch_slot &sl, float *d_P, fl
                       float lr, float reg, double *d_loss, bool item_grad_only = false)
 {
     const int64_t B = sl.B;
+    const int64_t k0 = sl.next_k;                 // which of the slot's batches this step consumes
+    const uint32_t *keys = sl.keys + 3 * B * k0, *vals = sl.vals + 3 * B * k0;
     RowCfg cfg;
     TF_REQUIRE(pick_cfg(d, all_aligned16({d_P, d_Q}), &cfg), TFREC_EUNSUP, "factor size d=%d is not supported (max 256)", d);
     StepWs w;
     TF_TRY(step_ws_carve(ctx, B, d, cfg, &w));
-    BprParams a{d_P, d_Q, d_b, w.stage, w.sbuf, sl.pair, (uint32_t)U, d, d / cfg.vec, lr, reg};
+    BprParams a{d_P, d_Q, d_b, w.stage, w.sbuf, sl.pair + B * k0, (uint32_t)U, d, d / cfg.vec, lr, reg, sl.kmask};
     const bool want_loss = d_loss != nullptr;
     return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC>() -> int {
         if (want_loss) {
-            TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, true>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, true,
+            TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, true>{a}, w, keys, vals, 0, B, w.n_tiles_u, w.blocks_u, true,
                             "user_tile", "user_fixup"));
             loss_finalize_kernel<2><<<1, 256, 0, ctx->stream>>>(w.loss_part, w.blocks_u, d_loss);
             TF_HIP(hipGetLastError());
         } else {
-            TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, false>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, false,
+            TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, false>{a}, w, keys, vals, 0, B, w.n_tiles_u, w.blocks_u, false,
                             "user_tile", "user_fixup"));
         }
         if (item_grad_only)
-            return run_pass(ctx, BprItemPol<LPR, NCH, VEC, true>{a}, w, sl.keys, sl.vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false,
+            return run_pass(ctx, BprItemPol<LPR, NCH, VEC, true>{a}, w, keys, vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false,
                             "item_tile", "item_fixup");
-        return run_pass(ctx, BprItemPol<LPR, NCH, VEC>{a}, w, sl.keys, sl.vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false, "item_tile",
+        return run_pass(ctx, BprItemPol<LPR, NCH, VEC>{a}, w, keys, vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false, "item_tile",
                         "item_fixup");
     });
 }
@@ -741,16 +756,18 @@ extern "C" int tfrec_rows_sgd_apply(tfrec_ctx *ctx, float *d_Q, float *d_b, int6
     const size_t rowf = (size_t)cfg.lpr * cfg.nch * cfg.vec;
     const int end_bit = bits_for((uint64_t)I);
     const size_t sort_bytes = tfrec_sort_temp_bytes((size_t)n, end_bit);
-    const size_t need = 4 * tf_align(4 * (size_t)n) + tf_align(sort_bytes) + tf_align(sizeof(float) * 2 * tiles * rowf) +
-                        tf_align(sizeof(float4) * 2 * tiles) + tf_align(4 * tiles) + 8192;
+    const int64_t slots = 2 * tiles + tiles / GPB + 2;
+    const size_t need = 4 * tf_align(4 * (size_t)n) + tf_align(sort_bytes) + tf_align(sizeof(float) * slots * rowf) +
+                        tf_align(sizeof(float4) * slots) + tf_align(4 * tiles) + 8192;
     TF_TRY(tfrec_ws_require(ctx, ctx->ws_used + need));
     uint32_t *keys_in = (uint32_t *)tfrec_ws_take(ctx, 4 * (size_t)n), *vals_in = (uint32_t *)tfrec_ws_take(ctx, 4 * (size_t)n);
     uint32_t *keys = (uint32_t *)tfrec_ws_take(ctx, 4 * (size_t)n), *vals = (uint32_t *)tfrec_ws_take(ctx, 4 * (size_t)n);
     void *sort_tmp = tfrec_ws_take(ctx, sort_bytes);
     StepWs w{};
-    w.part_rows = (float *)tfrec_ws_take(ctx, sizeof(float) * 2 * tiles * rowf);
-    w.part_sc = (float4 *)tfrec_ws_take(ctx, sizeof(float4) * 2 * tiles);
+    w.part_rows = (float *)tfrec_ws_take(ctx, sizeof(float) * slots * rowf);
+    w.part_sc = (float4 *)tfrec_ws_take(ctx, sizeof(float4) * slots);
     w.tile_flags = (uint32_t *)tfrec_ws_take(ctx, 4 * tiles);
+    w.blk_slot0 = 2 * tiles;
     TF_REQUIRE(w.tile_flags != nullptr, TFREC_ENOMEM, "internal: workspace carve failed");
     const int64_t n_tiles = (n + CH - 1) / CH;
     const int blocks = (int)((n_tiles + GPB - 1) / GPB);
@@ -784,8 +801,15 @@ extern "C" int tfrec_bpr_sgd_step(tfrec_ctx *ctx, float *d_P, float *d_Q, float 
 extern "C" int tfrec_batch_prepare(tfrec_ctx *ctx, int slot, int64_t U, int64_t I, const int32_t *d_users, const int32_t *d_pos,
                                    const int32_t *d_neg, int64_t B)
 {
+    return tfrec_batch_prepare_many(ctx, slot, U, I, d_users, d_pos, d_neg, B, 1);
+}
+
+extern "C" int tfrec_batch_prepare_many(tfrec_ctx *ctx, int slot, int64_t U, int64_t I, const int32_t *d_users,
+                                        const int32_t *d_pos, const int32_t *d_neg, int64_t B, int K)
+{
     TF_TRY(tfrec_ctx_enter(ctx));
     TF_REQUIRE(slot == 0 || slot == 1, TFREC_EINVAL, "slot must be 0 or 1");
+    TF_REQUIRE(K >= 1 && K <= 64, TFREC_EINVAL, "between 1 and 64 batches per preparation");
     TF_REQUIRE(U > 0 && I > 0 && U < (1ll << 31) && I < (1ll << 31), TFREC_EINVAL, "bad table shape");
     TF_REQUIRE(B >= 1 && B < (1ll << 30) && d_users && d_pos && d_neg, TFREC_EINVAL, "bad batch");
     if (!ctx->aux_stream) TF_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
@@ -799,7 +823,7 @@ extern "C" int tfrec_batch_prepare(tfrec_ctx *ctx, int slot, int64_t U, int64_t 
     TF_HIP(hipEventRecord(ctx->fork_event, ctx->stream));
     TF_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->fork_event, 0));
     sl.B = -1;
-    TF_TRY(slot_prepare(ctx, sl, ctx->aux_stream, d_users, d_pos, d_neg, B, U, I));
+    TF_TRY(slot_prepare(ctx, sl, ctx->aux_stream, d_users, d_pos, d_neg, B, U, I, K));
     TF_HIP(hipEventRecord(sl.ready, ctx->aux_stream));
     return TFREC_OK;
 }
@@ -817,9 +841,11 @@ extern "C" int tfrec_bpr_sgd_step_prepared(tfrec_ctx *ctx, int slot, float *d_P,
     tfrec_marks_reset(ctx);
     tfrec_mark(ctx, "start");
     const int rc = bpr_passes(ctx, sl, d_P, d_Q, d_b, U, d, lr, reg, d_loss);
-    TF_HIP(hipEventRecord(sl.released, ctx->stream));
-    sl.has_released = true;
-    sl.B = -1;      // consumed
+    if (++sl.next_k >= sl.K) {      // the last batch of the slot: its arrays may be overwritten once this step is done
+        TF_HIP(hipEventRecord(sl.released, ctx->stream));
+        sl.has_released = true;
+        sl.B = -1;
+    }
     return rc;
 }
 

@@ -187,6 +187,13 @@ class Device:
         B = _shape(users)[0]
         _lib.check(self.lib.tfrec_batch_prepare(self.h, int(slot), int(U), int(I), _ptr(users), _ptr(pos), _ptr(neg), B))
 
+    def prepare_batches(self, slot, U, I, users, pos, neg, K):
+        """Sorts K consecutive batches (arrays of K*B triples) at once; K prepared steps consume them."""
+        n = _shape(users)[0]
+        if n % K:
+            raise ValueError("%d triples are not %d equal batches" % (n, K))
+        _lib.check(self.lib.tfrec_batch_prepare_many(self.h, int(slot), int(U), int(I), _ptr(users), _ptr(pos), _ptr(neg), n // K, int(K)))
+
     def bpr_sgd_step_prepared(self, slot, P, Q, b, lr, reg, loss=None):
         U, d = _shape(P)
         I = _shape(Q)[0]

@@ -63,14 +63,19 @@ def main():
         def batch(s):
             o = (s % 4) * B
             return users[o:o + B], pos[o:o + B], neg[o:o + B]
-        dev.prepare_batch(0, a.U, a.I, *batch(0))
-        e0.record()
-        for s in range(a.steps):
-            dev.prepare_batch((s + 1) & 1, a.U, a.I, *batch(s + 1))
-            dev.bpr_sgd_step_prepared(s & 1, P, Q, b, 0.01, 0.05)
-        e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / a.steps
-        print(f"B={B}: plain {ms_plain:.3f} ms/step, pipelined {ms:.3f} ms/step")
+        for K in (1, 2, 4):
+            grp = (users[:K * B], pos[:K * B], neg[:K * B])
+            dev.prepare_batches(0, a.U, a.I, *grp, K)
+            e0.record()
+            nst = (a.steps // K) * K
+            for s in range(nst):
+                g, r = divmod(s, K)
+                if r == 0:
+                    dev.prepare_batches((g + 1) & 1, a.U, a.I, *grp, K)
+                dev.bpr_sgd_step_prepared(g & 1, P, Q, b, 0.01, 0.05)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / nst
+            print(f"B={B}: plain {ms_plain:.3f} ms/step, pipelined K={K} {ms:.3f} ms/step")
         rate = B / ms * 1e3
         alg = (24 * a.d + 28) * rate / 1e12
         dev.set_profiling(True)
