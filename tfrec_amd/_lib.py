@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtfrec_amd.so")
+# TFREC_AMD_LIB names another build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("TFREC_AMD_LIB") or os.path.join(_HERE, "lib", "libtfrec_amd.so")
 
 OK, EINVAL, EHIP, ENOMEM, EINDEX, EUNSUP = 0, -1, -2, -3, -4, -5
 SCORE_F32, SCORE_BF16 = 0, 1

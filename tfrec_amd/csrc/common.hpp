@@ -49,7 +49,7 @@ struct tfrec_batch_slot {
     int K = 1, next_k = 0;                   // batches sorted together / next one to consume
     uint32_t kmask = 0xffffffffu;            // key bits below the batch number
     uint32_t *keys = nullptr, *vals = nullptr;   // [3B] sorted: user side [0,B), item side [B,3B)
-    uint2 *pair = nullptr;
+    uint2 *pair = nullptr;                   // [K*B] (i, j) of every triple
     hipEvent_t ready = nullptr;              // recorded on the auxiliary stream after preparation
     hipEvent_t released = nullptr;           // recorded on the main stream after the step that consumed the slot
     bool has_released = false;
@@ -114,19 +114,39 @@ __device__ __forceinline__ float lane_xor(float v)
     }
 }
 
+// Lane permutations inside a row of 16 lanes done by the data-parallel-primitive path of the vector
+// ALU (no LDS round trip).  CTRL: 0xB1 swaps neighbours, 0x4E swaps pairs, 0x141 mirrors each half
+// row of 8 lanes, 0x140 mirrors the row of 16.
+template <int CTRL>
+__device__ __forceinline__ float lane_dpp(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
 // Sum over an aligned group of LPR lanes; every lane of the group gets the total.  The
-// combination order is fixed, so the result does not depend on scheduling.
+// combination order is fixed, so the result does not depend on scheduling.  After the first two
+// steps all lanes of a quad hold the same value, so the mirror permutations pair every lane with a
+// lane that holds what its XOR partner holds: the sums equal those of an XOR butterfly, bit for bit.
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v)
 {
-    if constexpr (LPR > 1) v += lane_xor<1>(v);
-    if constexpr (LPR > 2) v += lane_xor<2>(v);
-    if constexpr (LPR > 4) v += lane_xor<4>(v);
-    if constexpr (LPR > 8) v += lane_xor<8>(v);
+    if constexpr (LPR > 1) v += lane_dpp<0xB1>(v);
+    if constexpr (LPR > 2) v += lane_dpp<0x4E>(v);
+    if constexpr (LPR > 4) v += lane_dpp<0x141>(v);
+    if constexpr (LPR > 8) v += lane_dpp<0x140>(v);
     if constexpr (LPR > 16) v += lane_xor<16>(v);
     if constexpr (LPR > 32) v += lane_xor<32>(v);
     return v;
 }
+
+// Row geometry of a kernel configuration.  FULL: the factor size is exactly LPR*NCH*VEC, so row
+// strides and chunk counts are compile-time constants (shifts instead of 64-bit multiplies, no
+// per-lane bounds tests); otherwise the run-time values are used.
+template <int LPR, int NCH, int VEC, bool FULL>
+struct RowDims {
+    __device__ __forceinline__ static int d(int rt) { return FULL ? LPR * NCH * VEC : rt; }
+    __device__ __forceinline__ static int nchunk(int rt) { return FULL ? LPR * NCH : rt; }
+};
 
 // Read lane `src` (0..LPR-1, relative to the group) of every aligned LPR-lane group.
 template <int LPR>
@@ -249,7 +269,8 @@ struct Row {
 __device__ __forceinline__ float sigmoid_neg(float z)   // sigma(-z)
 {
     const float e = __expf(-fabsf(z));
-    return z >= 0.f ? e / (1.f + e) : 1.f / (1.f + e);
+    const float r = __builtin_amdgcn_rcpf(1.f + e);   // 1 ulp; 1 + e lies in [1, 2]
+    return z >= 0.f ? e * r : r;
 }
 __device__ __forceinline__ float softplus_neg(float z)  // log(1 + exp(-z))
 {

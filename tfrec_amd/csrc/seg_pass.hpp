@@ -140,36 +140,56 @@ __global__ __launch_bounds__(256) void seg_tile_kernel(Pol pol, const uint32_t *
         const uint32_t key_next = a + cnt < n ? keys[base + a + cnt] : NOKEY;
         uint32_t tail = 0;
 
-        uint4 en = ent[g][0];
-        typename Pol::Occ nx = pol.load_occ(en, gl);
-        typename Pol::Seg nseg = pol.load_seg(en.x, gl);
-        typename Pol::Seg seg = nseg;
-        bool lead_open = (en.x == key_prev);
-        uint32_t cur_key = en.x;
-
-        for (int e = 0; e < cnt; ++e) {
-            const typename Pol::Occ cur = nx;
-            if (en.x != cur_key) {
-                // the previous segment ended inside this tile
-                if (lead_open) {
-                    part_store<RowT, LPR, NCH, VEC>(part_rows, part_sc, 2 * w, acc, gl);
-                    lead_kind = LEAD_END;
-                } else {
-                    pol.apply(cur_key, &seg, acc, gl);
+        // Occurrences are taken DEPTH at a time: all their gathers (and the rows of the segments that
+        // start among them) are issued before the first is used, so a lane group keeps DEPTH row
+        // gathers in flight instead of one.
+        constexpr int DEPTH = Pol::DEPTH;
+        static_assert(CH % DEPTH == 0, "a tile holds a whole number of gather groups");
+        uint32_t cur_key = ent[g][0].x;
+        bool lead_open = (cur_key == key_prev);
+        typename Pol::Seg seg = pol.load_seg(cur_key, gl);
+        uint32_t seg_key = cur_key;          // key of the most recently requested segment row
+        // WHOLE: the tile has all CH occurrences (every tile but the last one of a pass), no bounds tests.
+        auto run = [&]<bool WHOLE>() {
+#pragma unroll 1
+            for (int c0 = 0; c0 < (WHOLE ? CH : cnt); c0 += DEPTH) {
+                uint4 en[DEPTH];
+                typename Pol::Occ oc[DEPTH];
+                typename Pol::Seg sg[DEPTH];
+                // (slots past the end of a short last tile repeat its last occurrence: loaded, never used)
+#pragma unroll
+                for (int q = 0; q < DEPTH; ++q) {
+                    en[q] = ent[g][(WHOLE || c0 + q < cnt) ? c0 + q : cnt - 1];
+                    oc[q] = pol.load_occ(en[q], gl);
                 }
-                lead_open = false;
-                cur_key = en.x;
-                seg = nseg;
-                acc.clear();
+#pragma unroll
+                for (int q = 0; q < DEPTH; ++q) {
+                    if (en[q].x != seg_key) sg[q] = pol.load_seg(en[q].x, gl);
+                    seg_key = en[q].x;
+                }
+#pragma unroll
+                for (int q = 0; q < DEPTH; ++q) {
+                    if (WHOLE || c0 + q < cnt) {
+                        if (en[q].x != cur_key) {
+                            // the previous segment ended inside this tile
+                            if (lead_open) {
+                                part_store<RowT, LPR, NCH, VEC>(part_rows, part_sc, 2 * w, acc, gl);
+                                lead_kind = LEAD_END;
+                            } else {
+                                pol.apply(cur_key, &seg, acc, gl);
+                            }
+                            lead_open = false;
+                            cur_key = en[q].x;
+                            seg = sg[q];
+                            acc.clear();
+                        }
+                        pol.compute(seg, oc[q], en[q], acc, loss, gl);
+                    }
+                }
             }
-            const uint4 en_now = en;
-            if (e + 1 < cnt) {   // issue the next occurrence's gathers before working on this one
-                en = ent[g][e + 1];
-                nx = pol.load_occ(en, gl);
-                if (en.x != cur_key) nseg = pol.load_seg(en.x, gl);
-            }
-            pol.compute(seg, cur, en_now, acc, loss, gl);
-        }
+        };
+        if (cnt == CH) run.template operator()<true>();
+        else run.template operator()<false>();
         // last segment of the tile
         const bool continues = (key_next == cur_key);
         if (lead_open) {

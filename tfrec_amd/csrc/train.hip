@@ -50,6 +50,14 @@ __global__ __launch_bounds__(256) void build_keys_kernel(const int32_t *__restri
 // BPR-SGD policies.  Reference math: model/base/MatrixFactorization.py:26-32 (score),
 // model/losses.py:4-12 (-log_sigmoid(x + 1e-7)), model/BPR.py:42-48 (loss, l2 on gathered rows, SGD)
 // ------------------------------------------------------------------------------------------
+// occurrences whose gathers a lane group keeps in flight (tile sizes are multiples of these)
+#ifndef TF_DEPTH_USER
+#define TF_DEPTH_USER 8
+#endif
+#ifndef TF_DEPTH_ITEM
+#define TF_DEPTH_ITEM 4
+#endif
+
 struct BprParams {
     float *P, *Q, *b;
     float *stage;        // [B, d] pre-step P[u] of every triple
@@ -61,10 +69,11 @@ struct BprParams {
     uint32_t kmask;      // sorted keys carry a batch number above these bits when several batches were sorted together
 };
 
-template <int LPR_, int NCH_, int VEC_, bool LOSS>
+template <int LPR_, int NCH_, int VEC_, bool FULL_, bool LOSS>
 struct BprUserPol {
-    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_ };
+    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_, DEPTH = TF_DEPTH_USER };
     using RowT = Row<LPR_, NCH_, VEC_>;
+    using DM = RowDims<LPR_, NCH_, VEC_, FULL_>;
     using Loss = LossAcc<LOSS ? 2 : 0>;
     BprParams a;
     struct Occ { RowT p, qi, qj; float bi, bj; };
@@ -78,9 +87,9 @@ struct BprUserPol {
     __device__ __forceinline__ Occ load_occ(uint4 en, int gl) const
     {
         Occ o;
-        o.p = RowT::load(a.P + (size_t)(en.x & a.kmask) * a.d, gl, a.nchunk);
-        o.qi = RowT::load(a.Q + (size_t)en.z * a.d, gl, a.nchunk);
-        o.qj = RowT::load(a.Q + (size_t)en.w * a.d, gl, a.nchunk);
+        o.p = RowT::load(a.P + (size_t)(en.x & a.kmask) * DM::d(a.d), gl, DM::nchunk(a.nchunk));
+        o.qi = RowT::load(a.Q + (size_t)en.z * DM::d(a.d), gl, DM::nchunk(a.nchunk));
+        o.qj = RowT::load(a.Q + (size_t)en.w * DM::d(a.d), gl, DM::nchunk(a.nchunk));
         o.bi = a.b[en.z];
         o.bj = a.b[en.w];
         return o;
@@ -95,7 +104,7 @@ struct BprUserPol {
         acc.v.fma(s, diff);          // user gradient is  -sum s*(q_i - q_j) + n*reg*p
         acc.cnt += 1;
         seg.p = o.p;
-        o.p.store(a.stage + (size_t)en.y * a.d, gl, a.nchunk);
+        o.p.store(a.stage + (size_t)en.y * DM::d(a.d), gl, DM::nchunk(a.nchunk));
         if (gl == 0) a.sbuf[en.y] = s;
         if constexpr (LOSS) {
             float r = o.p.dot_partial(o.p) + o.qi.dot_partial(o.qi) + o.qj.dot_partial(o.qj);
@@ -108,21 +117,22 @@ struct BprUserPol {
     }
     __device__ __forceinline__ void apply(uint32_t key, const Seg *seg, const Acc<RowT> &acc, int gl) const
     {
-        float *row = a.P + (size_t)(key & a.kmask) * a.d;
-        const RowT p = seg ? seg->p : RowT::load(row, gl, a.nchunk);
+        float *row = a.P + (size_t)(key & a.kmask) * DM::d(a.d);
+        const RowT p = seg ? seg->p : RowT::load(row, gl, DM::nchunk(a.nchunk));
         const float nreg = (float)acc.cnt * a.reg, lr = a.lr;
         const RowT out = p.map2(acc.v, [=](float pv, float av) { return fmaf(-lr, fmaf(nreg, pv, -av), pv); });
-        out.store(row, gl, a.nchunk);
+        out.store(row, gl, DM::nchunk(a.nchunk));
     }
 };
 
 // GRAD = false: apply the SGD update to Q, b.  GRAD = true: leave the summed gradient of every
 // distinct item in its Q row and b entry instead (the tables then hold fetched copies of rows
 // owned by other GPUs, and the sums travel back to the owners).
-template <int LPR_, int NCH_, int VEC_, bool GRAD = false>
+template <int LPR_, int NCH_, int VEC_, bool FULL_, bool GRAD = false>
 struct BprItemPol {
-    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_ };
+    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_, DEPTH = TF_DEPTH_ITEM };
     using RowT = Row<LPR_, NCH_, VEC_>;
+    using DM = RowDims<LPR_, NCH_, VEC_, FULL_>;
     using Loss = LossAcc<0>;
     BprParams a;
     struct Occ { RowT p; float s; };
@@ -133,14 +143,14 @@ struct BprItemPol {
     {
         const uint32_t t = en.y >> 1;
         Occ o;
-        o.p = RowT::load(a.stage + (size_t)t * a.d, gl, a.nchunk);
+        o.p = RowT::load(a.stage + (size_t)t * DM::d(a.d), gl, DM::nchunk(a.nchunk));
         o.s = a.sbuf[t];
         return o;
     }
     __device__ __forceinline__ Seg load_seg(uint32_t key, int gl) const
     {
         const uint32_t it = (key & a.kmask) - a.U;
-        return Seg{RowT::load(a.Q + (size_t)it * a.d, gl, a.nchunk), a.b[it]};
+        return Seg{RowT::load(a.Q + (size_t)it * DM::d(a.d), gl, DM::nchunk(a.nchunk)), a.b[it]};
     }
     __device__ __forceinline__ void compute(Seg &, const Occ &o, uint4 en, Acc<RowT> &acc, Loss &, int) const
     {
@@ -152,17 +162,17 @@ struct BprItemPol {
     __device__ __forceinline__ void apply(uint32_t key, const Seg *seg, const Acc<RowT> &acc, int gl) const
     {
         const uint32_t it = (key & a.kmask) - a.U;
-        float *row = a.Q + (size_t)it * a.d;
-        const RowT q = seg ? seg->q : RowT::load(row, gl, a.nchunk);
+        float *row = a.Q + (size_t)it * DM::d(a.d);
+        const RowT q = seg ? seg->q : RowT::load(row, gl, DM::nchunk(a.nchunk));
         const float bk = seg ? seg->bk : a.b[it];
         const float nreg = (float)acc.cnt * a.reg, lr = a.lr;
         if constexpr (GRAD) {
             const RowT out = q.map2(acc.v, [=](float qv, float av) { return fmaf(nreg, qv, -av); });
-            out.store(row, gl, a.nchunk);
+            out.store(row, gl, DM::nchunk(a.nchunk));
             if (gl == 0) a.b[it] = fmaf(nreg, bk, -acc.s0);
         } else {
             const RowT out = q.map2(acc.v, [=](float qv, float av) { return fmaf(-lr, fmaf(nreg, qv, -av), qv); });
-            out.store(row, gl, a.nchunk);
+            out.store(row, gl, DM::nchunk(a.nchunk));
             if (gl == 0) a.b[it] = fmaf(-lr, fmaf(nreg, bk, -acc.s0), bk);
         }
     }
@@ -176,10 +186,11 @@ struct RowsApplyParams {
     float lr;
 };
 
-template <int LPR_, int NCH_, int VEC_>
+template <int LPR_, int NCH_, int VEC_, bool FULL_>
 struct RowsApplyPol {
-    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_ };
+    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_, DEPTH = 8 };
     using RowT = Row<LPR_, NCH_, VEC_>;
+    using DM = RowDims<LPR_, NCH_, VEC_, FULL_>;
     using Loss = LossAcc<0>;
     RowsApplyParams a;
     struct Occ { RowT g; float gb; };
@@ -187,11 +198,11 @@ struct RowsApplyPol {
     __device__ __forceinline__ uint4 entry(uint32_t key, uint32_t val, int64_t) const { return make_uint4(key, val, 0, 0); }
     __device__ __forceinline__ Occ load_occ(uint4 en, int gl) const
     {
-        return Occ{RowT::load(a.grad_rows + (size_t)en.y * a.d, gl, a.nchunk), a.grad_b[en.y]};
+        return Occ{RowT::load(a.grad_rows + (size_t)en.y * DM::d(a.d), gl, DM::nchunk(a.nchunk)), a.grad_b[en.y]};
     }
     __device__ __forceinline__ Seg load_seg(uint32_t key, int gl) const
     {
-        return Seg{RowT::load(a.Q + (size_t)key * a.d, gl, a.nchunk), a.b[key]};
+        return Seg{RowT::load(a.Q + (size_t)key * DM::d(a.d), gl, DM::nchunk(a.nchunk)), a.b[key]};
     }
     __device__ __forceinline__ void compute(Seg &, const Occ &o, uint4, Acc<RowT> &acc, Loss &, int) const
     {
@@ -201,11 +212,11 @@ struct RowsApplyPol {
     }
     __device__ __forceinline__ void apply(uint32_t key, const Seg *seg, const Acc<RowT> &acc, int gl) const
     {
-        float *row = a.Q + (size_t)key * a.d;
-        const RowT q = seg ? seg->q : RowT::load(row, gl, a.nchunk);
+        float *row = a.Q + (size_t)key * DM::d(a.d);
+        const RowT q = seg ? seg->q : RowT::load(row, gl, DM::nchunk(a.nchunk));
         const float bk = seg ? seg->bk : a.b[key];
         const float lr = a.lr;
-        q.map2(acc.v, [=](float qv, float gv) { return fmaf(-lr, gv, qv); }).store(row, gl, a.nchunk);
+        q.map2(acc.v, [=](float qv, float gv) { return fmaf(-lr, gv, qv); }).store(row, gl, DM::nchunk(a.nchunk));
         if (gl == 0) a.b[key] = fmaf(-lr, acc.s0, bk);
     }
 };
@@ -248,10 +259,11 @@ __device__ __forceinline__ float clip_softplus_neg(float r) { return softplus_ne
 
 // phase 1, user side: s_t and delta_P rows (P is not modified in this phase, so the item side
 // gathers P[u] straight from the table)
-template <int LPR_, int NCH_, int VEC_>
+template <int LPR_, int NCH_, int VEC_, bool FULL_>
 struct AprUser1Pol {
-    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_ };
+    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_, DEPTH = 4 };
     using RowT = Row<LPR_, NCH_, VEC_>;
+    using DM = RowDims<LPR_, NCH_, VEC_, FULL_>;
     using Loss = LossAcc<0>;
     AprParams a;
     struct Occ { RowT p, qi, qj; float bi, bj; };
@@ -264,9 +276,9 @@ struct AprUser1Pol {
     __device__ __forceinline__ Occ load_occ(uint4 en, int gl) const
     {
         Occ o;
-        o.p = RowT::load(a.P + (size_t)en.x * a.d, gl, a.nchunk);
-        o.qi = RowT::load(a.Q + (size_t)en.z * a.d, gl, a.nchunk);
-        o.qj = RowT::load(a.Q + (size_t)en.w * a.d, gl, a.nchunk);
+        o.p = RowT::load(a.P + (size_t)en.x * DM::d(a.d), gl, DM::nchunk(a.nchunk));
+        o.qi = RowT::load(a.Q + (size_t)en.z * DM::d(a.d), gl, DM::nchunk(a.nchunk));
+        o.qj = RowT::load(a.Q + (size_t)en.w * DM::d(a.d), gl, DM::nchunk(a.nchunk));
         o.bi = a.b[en.z];
         o.bj = a.b[en.w];
         return o;
@@ -287,15 +299,16 @@ struct AprUser1Pol {
         const float sc = a.eps * rsqrtf(fmaxf(n2, 1e-12f));
         RowT out = RowT::zero();
         out.fma(sc, acc.v);
-        out.store(a.dP + (size_t)key * a.d, gl, a.nchunk);
+        out.store(a.dP + (size_t)key * DM::d(a.d), gl, DM::nchunk(a.nchunk));
     }
 };
 
 // phase 1, item side: delta_Q rows, raw bias gradient into db, and sum of its squares
-template <int LPR_, int NCH_, int VEC_>
+template <int LPR_, int NCH_, int VEC_, bool FULL_>
 struct AprItem1Pol {
-    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_ };
+    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_, DEPTH = 8 };
     using RowT = Row<LPR_, NCH_, VEC_>;
+    using DM = RowDims<LPR_, NCH_, VEC_, FULL_>;
     using Loss = LossAcc<0>;
     AprParams a;
     struct Occ { RowT p; float s; };
@@ -306,7 +319,7 @@ struct AprItem1Pol {
         const uint32_t t = en.y >> 1;
         const int32_t ur = a.users[t];
         const uint32_t u = ur < 0 ? 0u : ((uint32_t)ur >= a.U ? a.U - 1 : (uint32_t)ur);
-        return Occ{RowT::load(a.P + (size_t)u * a.d, gl, a.nchunk), a.sbuf[t]};
+        return Occ{RowT::load(a.P + (size_t)u * DM::d(a.d), gl, DM::nchunk(a.nchunk)), a.sbuf[t]};
     }
     __device__ __forceinline__ Seg load_seg(uint32_t, int) const { return Seg{0}; }
     __device__ __forceinline__ void compute(Seg &, const Occ &o, uint4 en, Acc<RowT> &acc, Loss &, int) const
@@ -323,16 +336,17 @@ struct AprItem1Pol {
         const float sc = a.eps * rsqrtf(fmaxf(n2, 1e-12f));
         RowT out = RowT::zero();
         out.fma(sc, acc.v);
-        out.store(a.dQ + (size_t)it * a.d, gl, a.nchunk);
+        out.store(a.dQ + (size_t)it * DM::d(a.d), gl, DM::nchunk(a.nchunk));
         if (gl == 0) a.db[it] = acc.s0;     // scaled once the global norm is known
     }
 };
 
 // phase 2, user side
-template <int LPR_, int NCH_, int VEC_, bool LOSS>
+template <int LPR_, int NCH_, int VEC_, bool FULL_, bool LOSS>
 struct AprUser2Pol {
-    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_ };
+    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_, DEPTH = 2 };
     using RowT = Row<LPR_, NCH_, VEC_>;
+    using DM = RowDims<LPR_, NCH_, VEC_, FULL_>;
     using Loss = LossAcc<LOSS ? 3 : 0>;
     AprParams a;
     struct Occ { RowT p, dp, qi, qj, dqi, dqj; float bi, bj, dbi, dbj; };
@@ -345,12 +359,12 @@ struct AprUser2Pol {
     __device__ __forceinline__ Occ load_occ(uint4 en, int gl) const
     {
         Occ o;
-        o.p = RowT::load(a.P + (size_t)en.x * a.d, gl, a.nchunk);
-        o.dp = RowT::load(a.dP + (size_t)en.x * a.d, gl, a.nchunk);
-        o.qi = RowT::load(a.Q + (size_t)en.z * a.d, gl, a.nchunk);
-        o.qj = RowT::load(a.Q + (size_t)en.w * a.d, gl, a.nchunk);
-        o.dqi = RowT::load(a.dQ + (size_t)en.z * a.d, gl, a.nchunk);
-        o.dqj = RowT::load(a.dQ + (size_t)en.w * a.d, gl, a.nchunk);
+        o.p = RowT::load(a.P + (size_t)en.x * DM::d(a.d), gl, DM::nchunk(a.nchunk));
+        o.dp = RowT::load(a.dP + (size_t)en.x * DM::d(a.d), gl, DM::nchunk(a.nchunk));
+        o.qi = RowT::load(a.Q + (size_t)en.z * DM::d(a.d), gl, DM::nchunk(a.nchunk));
+        o.qj = RowT::load(a.Q + (size_t)en.w * DM::d(a.d), gl, DM::nchunk(a.nchunk));
+        o.dqi = RowT::load(a.dQ + (size_t)en.z * DM::d(a.d), gl, DM::nchunk(a.nchunk));
+        o.dqj = RowT::load(a.dQ + (size_t)en.w * DM::d(a.d), gl, DM::nchunk(a.nchunk));
         o.bi = a.b[en.z]; o.bj = a.b[en.w];
         o.dbi = a.db[en.z]; o.dbj = a.db[en.w];
         return o;
@@ -375,37 +389,38 @@ struct AprUser2Pol {
         RowT c = RowT::zero();
         c.fma(s, o.p);
         c.fma(sa, pa);
-        c.store(a.stage + (size_t)en.y * a.d, gl, a.nchunk);
+        c.store(a.stage + (size_t)en.y * DM::d(a.d), gl, DM::nchunk(a.nchunk));
         if (gl == 0) a.sbuf[en.y] = s + sa;
         if constexpr (LOSS) {
             float m = o.p.dot_partial(o.p) + o.qi.dot_partial(o.qi) + o.qj.dot_partial(o.qj);
             if (gl == 0) {
                 loss.t[0] += clip_softplus_neg(r);
                 loss.t[1] += clip_softplus_neg(ra);
-                m += (float)a.d * (o.bi * o.bi + o.bj * o.bj);
+                m += (float)DM::d(a.d) * (o.bi * o.bi + o.bj * o.bj);
             }
             loss.t[2] += m;
         }
     }
     __device__ __forceinline__ void apply(uint32_t key, const Seg *seg, const Acc<RowT> &acc, int gl) const
     {
-        float *row = a.P + (size_t)key * a.d, *arow = a.accP + (size_t)key * a.d;
-        const RowT p = seg ? seg->p : RowT::load(row, gl, a.nchunk);
-        const RowT ac = RowT::load(arow, gl, a.nchunk);
+        float *row = a.P + (size_t)key * DM::d(a.d), *arow = a.accP + (size_t)key * DM::d(a.d);
+        const RowT p = seg ? seg->p : RowT::load(row, gl, DM::nchunk(a.nchunk));
+        const RowT ac = RowT::load(arow, gl, DM::nchunk(a.nchunk));
         const RowT an = ac.map2(acc.v, [](float av, float g) { return fmaf(g, g, av); });
-        an.store(arow, gl, a.nchunk);
+        an.store(arow, gl, DM::nchunk(a.nchunk));
         const float lr = a.lr;
         // w -= lr * g / sqrt(acc_new)
         RowT step = acc.v.map2(an, [=](float g, float av) { return lr * g / sqrtf(av); });
-        (p - step).store(row, gl, a.nchunk);
+        (p - step).store(row, gl, DM::nchunk(a.nchunk));
     }
 };
 
 // phase 2, item side
-template <int LPR_, int NCH_, int VEC_>
+template <int LPR_, int NCH_, int VEC_, bool FULL_>
 struct AprItem2Pol {
-    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_ };
+    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_, DEPTH = 8 };
     using RowT = Row<LPR_, NCH_, VEC_>;
+    using DM = RowDims<LPR_, NCH_, VEC_, FULL_>;
     using Loss = LossAcc<0>;
     AprParams a;
     struct Occ { RowT c; float s; };
@@ -414,12 +429,12 @@ struct AprItem2Pol {
     __device__ __forceinline__ Occ load_occ(uint4 en, int gl) const
     {
         const uint32_t t = en.y >> 1;
-        return Occ{RowT::load(a.stage + (size_t)t * a.d, gl, a.nchunk), a.sbuf[t]};
+        return Occ{RowT::load(a.stage + (size_t)t * DM::d(a.d), gl, DM::nchunk(a.nchunk)), a.sbuf[t]};
     }
     __device__ __forceinline__ Seg load_seg(uint32_t key, int gl) const
     {
         const uint32_t it = key - a.U;
-        return Seg{RowT::load(a.Q + (size_t)it * a.d, gl, a.nchunk), a.b[it]};
+        return Seg{RowT::load(a.Q + (size_t)it * DM::d(a.d), gl, DM::nchunk(a.nchunk)), a.b[it]};
     }
     __device__ __forceinline__ void compute(Seg &, const Occ &o, uint4 en, Acc<RowT> &acc, Loss &, int) const
     {
@@ -431,19 +446,19 @@ struct AprItem2Pol {
     __device__ __forceinline__ void apply(uint32_t key, const Seg *seg, const Acc<RowT> &acc, int gl) const
     {
         const uint32_t it = key - a.U;
-        float *row = a.Q + (size_t)it * a.d, *arow = a.accQ + (size_t)it * a.d;
-        const RowT q = seg ? seg->q : RowT::load(row, gl, a.nchunk);
+        float *row = a.Q + (size_t)it * DM::d(a.d), *arow = a.accQ + (size_t)it * DM::d(a.d);
+        const RowT q = seg ? seg->q : RowT::load(row, gl, DM::nchunk(a.nchunk));
         const float bk = seg ? seg->bk : a.b[it];
         const float n = (float)acc.cnt, creg = a.reg_coef, lr = a.lr;
         // every occurrence adds creg*q (rows) and creg*d*b (bias) from the mean-square term
         const RowT g = acc.v.map2(q, [=](float gv, float qv) { return fmaf(n * creg, qv, gv); });
-        const RowT ac = RowT::load(arow, gl, a.nchunk);
+        const RowT ac = RowT::load(arow, gl, DM::nchunk(a.nchunk));
         const RowT an = ac.map2(g, [](float av, float gv) { return fmaf(gv, gv, av); });
-        an.store(arow, gl, a.nchunk);
+        an.store(arow, gl, DM::nchunk(a.nchunk));
         RowT step = g.map2(an, [=](float gv, float av) { return lr * gv / sqrtf(av); });
-        (q - step).store(row, gl, a.nchunk);
+        (q - step).store(row, gl, DM::nchunk(a.nchunk));
         if (gl == 0) {
-            const float gb = fmaf(n * creg * (float)a.d, bk, acc.s0);
+            const float gb = fmaf(n * creg * (float)DM::d(a.d), bk, acc.s0);
             const float abn = fmaf(gb, gb, a.accb[it]);
             a.accb[it] = abn;
             a.b[it] = bk - lr * gb / sqrtf(abn);
@@ -497,7 +512,7 @@ __global__ __launch_bounds__(256) void apr_bias_scale_kernel(const uint32_t *__r
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-struct RowCfg { int lpr, nch, vec; };
+struct RowCfg { int lpr, nch, vec; bool full; };   // full: d == lpr * nch * vec, row geometry known at compile time
 
 static bool pick_cfg(int d, bool aligned16, RowCfg *c)
 {
@@ -510,9 +525,10 @@ static bool pick_cfg(int d, bool aligned16, RowCfg *c)
         else if (n4 <= 32) c->lpr = 32;
         else if (n4 <= 64) c->lpr = 64;
         else return false;
+        c->full = (n4 == c->lpr);
         return true;
     }
-    c->vec = 1; c->lpr = 64;
+    c->vec = 1; c->lpr = 64; c->full = false;
     if (d <= 64) c->nch = 1;
     else if (d <= 128) c->nch = 2;
     else if (d <= 256) c->nch = 4;
@@ -520,22 +536,33 @@ static bool pick_cfg(int d, bool aligned16, RowCfg *c)
     return true;
 }
 
-// Calls f.template operator()<LPR,NCH,VEC>() for the chosen configuration.
-template <class F>
+// Calls f.template operator()<LPR,NCH,VEC,FULL>() for the chosen configuration.  WITH_FULL = false
+// never picks the compile-time-geometry variants (for kernels that gain nothing from them).
+template <bool WITH_FULL = true, class F>
 static int dispatch_cfg(const RowCfg &c, F &&f)
 {
     if (c.vec == 4) {
+        if constexpr (WITH_FULL) {
+            if (c.full) {
+                switch (c.lpr) {
+                    case 8: return f.template operator()<8, 1, 4, true>();
+                    case 16: return f.template operator()<16, 1, 4, true>();
+                    case 32: return f.template operator()<32, 1, 4, true>();
+                    case 64: return f.template operator()<64, 1, 4, true>();
+                }
+            }
+        }
         switch (c.lpr) {
-            case 8: return f.template operator()<8, 1, 4>();
-            case 16: return f.template operator()<16, 1, 4>();
-            case 32: return f.template operator()<32, 1, 4>();
-            case 64: return f.template operator()<64, 1, 4>();
+            case 8: return f.template operator()<8, 1, 4, false>();
+            case 16: return f.template operator()<16, 1, 4, false>();
+            case 32: return f.template operator()<32, 1, 4, false>();
+            case 64: return f.template operator()<64, 1, 4, false>();
         }
     } else {
         switch (c.nch) {
-            case 1: return f.template operator()<64, 1, 1>();
-            case 2: return f.template operator()<64, 2, 1>();
-            case 4: return f.template operator()<64, 4, 1>();
+            case 1: return f.template operator()<64, 1, 1, false>();
+            case 2: return f.template operator()<64, 2, 1, false>();
+            case 4: return f.template operator()<64, 4, 1, false>();
         }
     }
     tfrec_set_error("internal: no kernel configuration");
@@ -705,20 +732,20 @@ static int bpr_passes(tfrec_ctx *ctx, const tfrec_batch_slot &sl, float *d_P, fl
     TF_TRY(step_ws_carve(ctx, B, d, cfg, &w));
     BprParams a{d_P, d_Q, d_b, w.stage, w.sbuf, sl.pair + B * k0, (uint32_t)U, d, d / cfg.vec, lr, reg, sl.kmask};
     const bool want_loss = d_loss != nullptr;
-    return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC>() -> int {
+    return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC, bool FULL>() -> int {
         if (want_loss) {
-            TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, true>{a}, w, keys, vals, 0, B, w.n_tiles_u, w.blocks_u, true,
+            TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, FULL, true>{a}, w, keys, vals, 0, B, w.n_tiles_u, w.blocks_u, true,
                             "user_tile", "user_fixup"));
             loss_finalize_kernel<2><<<1, 256, 0, ctx->stream>>>(w.loss_part, w.blocks_u, d_loss);
             TF_HIP(hipGetLastError());
         } else {
-            TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, false>{a}, w, keys, vals, 0, B, w.n_tiles_u, w.blocks_u, false,
+            TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, FULL, false>{a}, w, keys, vals, 0, B, w.n_tiles_u, w.blocks_u, false,
                             "user_tile", "user_fixup"));
         }
         if (item_grad_only)
-            return run_pass(ctx, BprItemPol<LPR, NCH, VEC, true>{a}, w, keys, vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false,
+            return run_pass(ctx, BprItemPol<LPR, NCH, VEC, FULL, true>{a}, w, keys, vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false,
                             "item_tile", "item_fixup");
-        return run_pass(ctx, BprItemPol<LPR, NCH, VEC>{a}, w, keys, vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false, "item_tile",
+        return run_pass(ctx, BprItemPol<LPR, NCH, VEC, FULL>{a}, w, keys, vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false, "item_tile",
                         "item_fixup");
     });
 }
@@ -775,8 +802,8 @@ extern "C" int tfrec_rows_sgd_apply(tfrec_ctx *ctx, float *d_Q, float *d_b, int6
     TF_HIP(hipGetLastError());
     TF_TRY(tfrec_sort_pairs(sort_tmp, sort_bytes, keys_in, keys, vals_in, vals, (size_t)n, end_bit, ctx->stream));
     RowsApplyParams a{d_Q, d_b, d_grad_rows, d_grad_b, d, d / cfg.vec, lr};
-    return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC>() -> int {
-        return run_pass(ctx, RowsApplyPol<LPR, NCH, VEC>{a}, w, keys, vals, 0, n, n_tiles, blocks, false, "apply_tile", "apply_fixup");
+    return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC, bool FULL>() -> int {
+        return run_pass(ctx, RowsApplyPol<LPR, NCH, VEC, FULL>{a}, w, keys, vals, 0, n, n_tiles, blocks, false, "apply_tile", "apply_fixup");
     });
 }
 
@@ -879,11 +906,11 @@ extern "C" int tfrec_apr_adagrad_step(tfrec_ctx *ctx, float *d_P, float *d_Q, fl
     a.U = (uint32_t)U; a.d = d; a.nchunk = d / cfg.vec;
     a.lr = lr; a.reg_coef = (float)(4.0 * (double)reg / ((double)B * (double)d)); a.reg_adv = reg_adv; a.eps = eps;
     const bool want_loss = d_loss != nullptr;
-    return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC>() -> int {
+    return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC, bool FULL>() -> int {
         // phase 1: deltas
-        TF_TRY(run_pass(ctx, AprUser1Pol<LPR, NCH, VEC>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, false,
+        TF_TRY(run_pass(ctx, AprUser1Pol<LPR, NCH, VEC, FULL>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, false,
                         "delta_user_tile", "delta_user_fixup"));
-        TF_TRY(run_pass(ctx, AprItem1Pol<LPR, NCH, VEC>{a}, w, sl.keys, sl.vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false,
+        TF_TRY(run_pass(ctx, AprItem1Pol<LPR, NCH, VEC, FULL>{a}, w, sl.keys, sl.vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false,
                         "delta_item_tile", "delta_item_fixup"));
         const int nb = (int)((2 * B + 255) / 256 < 512 ? (2 * B + 255) / 256 : 512);
         apr_bias_norm_kernel<<<nb, 256, 0, ctx->stream>>>(sl.keys, B, 2 * B, (uint32_t)U, d_db, w.loss_part);
@@ -895,15 +922,15 @@ extern "C" int tfrec_apr_adagrad_step(tfrec_ctx *ctx, float *d_P, float *d_Q, fl
         tfrec_mark(ctx, "delta_bias_norm");
         // phase 2: Adagrad step at (Theta, delta)
         if (want_loss) {
-            TF_TRY(run_pass(ctx, AprUser2Pol<LPR, NCH, VEC, true>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, true,
+            TF_TRY(run_pass(ctx, AprUser2Pol<LPR, NCH, VEC, FULL, true>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, true,
                             "user_tile", "user_fixup"));
             loss_finalize_kernel<3><<<1, 256, 0, ctx->stream>>>(w.loss_part, w.blocks_u, w.scalars + 4);
             TF_HIP(hipGetLastError());
         } else {
-            TF_TRY(run_pass(ctx, AprUser2Pol<LPR, NCH, VEC, false>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, false,
+            TF_TRY(run_pass(ctx, AprUser2Pol<LPR, NCH, VEC, FULL, false>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, false,
                             "user_tile", "user_fixup"));
         }
-        TF_TRY(run_pass(ctx, AprItem2Pol<LPR, NCH, VEC>{a}, w, sl.keys, sl.vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false, "item_tile",
+        TF_TRY(run_pass(ctx, AprItem2Pol<LPR, NCH, VEC, FULL>{a}, w, sl.keys, sl.vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false, "item_tile",
                         "item_fixup"));
         if (want_loss) {
             // the third number is a mean over B*d entries
@@ -949,7 +976,7 @@ extern "C" int tfrec_mf_predict(tfrec_ctx *ctx, const float *d_P, const float *d
     if (n == 0) return TFREC_OK;
     RowCfg cfg;
     TF_REQUIRE(pick_cfg(d, all_aligned16({d_P, d_Q}), &cfg), TFREC_EUNSUP, "factor size d=%d is not supported (max 256)", d);
-    return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC>() -> int {
+    return dispatch_cfg<false>(cfg, [&]<int LPR, int NCH, int VEC, bool FULL>() -> int {
         const int64_t groups = (n + (256 / LPR) - 1) / (256 / LPR);
         const int blocks = (int)(groups < 4096 ? groups : 4096);
         predict_kernel<LPR, NCH, VEC><<<blocks, 256, 0, ctx->stream>>>(d_P, d_Q, d_b, (uint32_t)U, (uint32_t)I, d, d / VEC, d_users,
@@ -1016,7 +1043,7 @@ extern "C" int tfrec_dns_select(tfrec_ctx *ctx, const float *d_P, const float *d
     if (n_pos == 0) return TFREC_OK;
     RowCfg cfg;
     TF_REQUIRE(pick_cfg(d, all_aligned16({d_P, d_Q}), &cfg), TFREC_EUNSUP, "factor size d=%d is not supported (max 256)", d);
-    return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC>() -> int {
+    return dispatch_cfg<false>(cfg, [&]<int LPR, int NCH, int VEC, bool FULL>() -> int {
         const int64_t groups = (n_pos + (256 / LPR) - 1) / (256 / LPR);
         const int blocks = (int)(groups < 8192 ? groups : 8192);
         dns_select_kernel<LPR, NCH, VEC><<<blocks, 256, 0, ctx->stream>>>(d_P, d_Q, d_b, (uint32_t)U, (uint32_t)I, d, d / VEC, d_users,

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--dist", type=str, default="zipf")
     ap.add_argument("--eval-users", type=int, default=0)
     ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--plain-only", action="store_true", help="only the un-pipelined steps (for counter collection)")
     a = ap.parse_args()
     torch.cuda.set_device(0)
     cuda = torch.device("cuda:0")
@@ -59,6 +60,9 @@ def main():
             step(s)
         e1.record(); torch.cuda.synchronize()
         ms_plain = e0.elapsed_time(e1) / a.steps
+        if a.plain_only:
+            print(f"B={B}: plain {ms_plain:.3f} ms/step", flush=True)
+            continue
 
         def batch(s):
             o = (s % 4) * B
