@@ -93,6 +93,14 @@ int tfrec_mf_predict(tfrec_ctx *ctx, const float *d_P, const float *d_Q, const f
                      int64_t U, int64_t I, int d,
                      const int32_t *d_users, const int32_t *d_items, int64_t n, float *d_out);
 
+/* Stable sort of n (key, value) pairs of 32-bit words by the low key_bits bits of the key (higher
+ * key bits must be zero); not in place.  No counterpart in the reference, whose duplicate row ids
+ * are summed by TensorFlow's gather gradient (model/BPR.py:36-40 + tf.train optimizers): this is
+ * the index step every training entry point below runs first, exposed so callers and tests can
+ * use and check it on its own. */
+int tfrec_sort_pairs_u32(tfrec_ctx *ctx, const uint32_t *d_keys_in, const uint32_t *d_vals_in,
+                         uint32_t *d_keys_out, uint32_t *d_vals_out, int64_t n, int key_bits);
+
 /* ---- training steps ------------------------------------------------------------------------ */
 /* One BPR-MF minibatch step with plain SGD: the graph of model/BPR.py:36-48 (identical in
  * model/DNSBPR.py:35-47) executed by sess.run(self.update) at model/BPR.py:72.

@@ -232,3 +232,20 @@ def test_fill_uniform_is_counter_based(dev):
     c = dev.uniform((64000,), -0.05, 0.05, 2018).numpy()
     assert np.array_equal(a.ravel(), c)
     assert a.min() >= -0.05 and a.max() < 0.05 and abs(a.mean()) < 1e-3 and abs(a.std() - 0.1 / np.sqrt(12)) < 1e-3
+
+
+@pytest.mark.parametrize("n,bits", [(1, 1), (63, 5), (4096, 8), (4097, 13), (100003, 21), (3 * (1 << 20), 21), (300000, 32), (70000, 17)])
+def test_sort_pairs_is_a_stable_sort(dev, n, bits):
+    """The index sort under every training step, against numpy's stable sort (exact)."""
+    rng = np.random.default_rng(n + bits)
+    hi = (1 << bits) - 1
+    keys = rng.integers(0, hi + 1, n, dtype=np.uint64).astype(np.uint32)
+    if n > 1000:
+        keys[: n // 3] = keys[0]                      # a long run of one key
+        keys[n // 3: n // 2] &= np.uint32(0xff)       # and a crowded corner of the key space
+    vals = np.arange(n, dtype=np.uint32)
+    ko, vo = dev.sort_pairs(dev.array(keys, np.uint32), dev.array(vals, np.uint32), bits)
+    dev.synchronize()
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(ko.numpy(), keys[order])
+    assert np.array_equal(vo.numpy(), vals[order])

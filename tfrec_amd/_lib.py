@@ -42,6 +42,7 @@ SIGNATURES = {
     "tfrec_fill_uniform_at": (_int, [_p, _p, _i64, _f, _f, C.c_uint64, _i64]),
     "tfrec_fill_const": (_int, [_p, _p, _i64, _f]),
     "tfrec_mf_predict": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _i64, _p]),
+    "tfrec_sort_pairs_u32": (_int, [_p, _p, _p, _p, _p, _i64, _int]),
     "tfrec_bpr_sgd_step": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _i64, _f, _f, _p]),
     "tfrec_batch_prepare": (_int, [_p, _int, _i64, _i64, _p, _p, _p, _i64]),
     "tfrec_batch_prepare_many": (_int, [_p, _int, _i64, _i64, _p, _p, _p, _i64, _int]),

@@ -1,29 +1,295 @@
-// Stable LSD radix sort of (key, value) pairs on the device.  The duplicate-index reduction of
-// the training steps is built on it: occurrences sorted by row id become contiguous segments.
-// rocPRIM's device radix sort is used for this index-only step (8 bytes per element and pass);
-// the row traffic of a step is two orders of magnitude larger.
-#include <cstring>
-
-#include <rocprim/device/device_radix_sort.hpp>
-
+// Stable LSD radix sort of (key, value) pairs of 32-bit words on the device.  The duplicate-index
+// reduction of the training steps is built on it: occurrences sorted by row id become contiguous
+// segments, and stability keeps the occurrences of a row in batch order, so the order in which a
+// row's gradient terms are added is fixed.
+//
+// A batch is a few million pairs, far too few for a chained single-sweep sort to hide its
+// tile-to-tile dependency.  Every pass here is three short, fully parallel kernels instead:
+//   1. sort_hist_kernel     per-tile digit counts                  -> counts[digit][tile]
+//   2. sort_scan_kernel     exclusive prefix along every digit row  (in place) + digit totals
+//   3. sort_scatter_kernel  ranks the tile's pairs stably (wave-level digit matching), orders them
+//                           in LDS and writes every digit's run to its final place, coalesced
+// No kernel needs zeroed memory, so no memsets are enqueued.
 #include "common.hpp"
+
+// widest radix digit a pass may use
+#ifndef TF_SORT_RB_MAX
+#define TF_SORT_RB_MAX 8
+#endif
+#ifndef TF_SORT_ITEMS
+#define TF_SORT_ITEMS 8
+#endif
+
+namespace {
+
+constexpr int SORT_WAVES = 4;       // workgroups of 256 lanes
+
+// Exclusive prefix of one value per lane over the 256 lanes of a workgroup; *total = sum of all.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wave_sums /* [SORT_WAVES] in LDS */, uint32_t *total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+    }
+    if (lane == 63) wave_sums[w] = inc;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int i = 0; i < SORT_WAVES; ++i) {
+        const uint32_t s = wave_sums[i];
+        if (i < w) before += s;
+        all += s;
+    }
+    __syncthreads();      // wave_sums may be reused by the caller
+    *total = all;
+    return before + inc - v;
+}
+
+template <int RB, int ITEMS>
+__global__ __launch_bounds__(256) void sort_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n, int shift, uint32_t dmask,
+                                                        uint32_t *__restrict__ counts, uint32_t nblk)
+{
+    constexpr int BINS = 1 << RB, TILE = 256 * ITEMS;
+    __shared__ uint32_t h[SORT_WAVES][BINS];
+    for (int i = threadIdx.x; i < SORT_WAVES * BINS; i += 256) (&h[0][0])[i] = 0;
+    __syncthreads();
+    const int w = threadIdx.x >> 6;
+    const uint32_t base = blockIdx.x * (uint32_t)TILE;
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const uint32_t i = base + r * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&h[w][(keys[i] >> shift) & dmask], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < BINS; b += 256) {
+        uint32_t s = 0;
+#pragma unroll
+        for (int i = 0; i < SORT_WAVES; ++i) s += h[i][b];
+        counts[(size_t)b * nblk + blockIdx.x] = s;
+    }
+}
+
+// One workgroup per digit: counts[digit][0..nblk) becomes its exclusive prefix; digit_total[digit] = row sum.
+__global__ __launch_bounds__(256) void sort_scan_kernel(uint32_t *__restrict__ counts, uint32_t nblk, uint32_t *__restrict__ digit_total)
+{
+    __shared__ uint32_t wave_sums[SORT_WAVES];
+    uint32_t *row = counts + (size_t)blockIdx.x * nblk;
+    const uint32_t per = (nblk + 255) / 256;
+    const uint32_t lo = threadIdx.x * per, hi = lo + per < nblk ? lo + per : nblk;
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; ++i) s += row[i];
+    uint32_t total;
+    uint32_t run = block_excl_scan(s, wave_sums, &total);
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t v = row[i];
+        row[i] = run;
+        run += v;
+    }
+    if (threadIdx.x == 0) digit_total[blockIdx.x] = total;
+}
+
+template <int RB, int ITEMS>
+__global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+                                                           uint32_t *__restrict__ kout, uint32_t *__restrict__ vout, uint32_t n, int shift,
+                                                           uint32_t dmask, const uint32_t *__restrict__ prefix,
+                                                           const uint32_t *__restrict__ digit_total, uint32_t nblk)
+{
+    constexpr int BINS = 1 << RB, TILE = 256 * ITEMS, PER_WAVE = 64 * ITEMS;
+    constexpr int DPT = BINS >= 256 ? BINS / 256 : 1;       // digits per lane in the prefix steps
+    __shared__ uint32_t cnt[SORT_WAVES][BINS];   // per-wave digit counts, then each wave's first slot per digit
+    __shared__ uint32_t gofs[BINS];              // slot i of the ordered tile (digit d) goes to gofs[d] + i
+    __shared__ uint2 ordered[TILE];
+    __shared__ uint32_t wave_sums[SORT_WAVES];
+
+    for (int i = threadIdx.x; i < SORT_WAVES * BINS; i += 256) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t tile0 = blockIdx.x * (uint32_t)TILE;
+    const uint32_t wbase = tile0 + w * PER_WAVE;
+    uint32_t k[ITEMS], v[ITEMS], rank[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const uint32_t i = wbase + r * 64 + lane;
+        k[r] = i < n ? kin[i] : 0u;
+        v[r] = i < n ? vin[i] : 0u;
+    }
+    // Wave w holds PER_WAVE consecutive pairs, 64 consecutive ones per round.  Lanes with the same
+    // digit find each other with one ballot per digit bit; their order among themselves is lane
+    // order, and the lowest of them advances the wave's counter of that digit.
+    uint32_t *my_cnt = &cnt[w][0];
+    const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const bool valid = wbase + r * 64 + lane < n;
+        const uint32_t d = (k[r] >> shift) & dmask;
+        uint64_t m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t bal = __ballot(bit);
+            m &= bit ? bal : ~bal;
+        }
+        const uint32_t rk = (uint32_t)__popcll(m & below);
+        // (one LDS add-and-return per digit and round; a wave's LDS operations complete in issue
+        // order, so the rounds pipeline and the counts do not depend on timing)
+        uint32_t old = 0;
+        if (valid && rk == 0) old = atomicAdd(&my_cnt[d], (uint32_t)__popcll(m));
+        const int leader = m ? __ffsll((unsigned long long)m) - 1 : 0;
+        rank[r] = __shfl(old, leader, 64) + rk;
+    }
+    __syncthreads();
+
+    // per digit: where each wave's pairs start in the ordered tile, and where the tile's run goes
+    {
+        uint32_t c[DPT][SORT_WAVES], tot = 0, gt[DPT], gsum = 0;
+#pragma unroll
+        for (int j = 0; j < DPT; ++j) {
+            const int d = threadIdx.x * DPT + j;
+            gt[j] = 0;
+#pragma unroll
+            for (int i = 0; i < SORT_WAVES; ++i) c[j][i] = 0;
+            if (d < BINS) {
+#pragma unroll
+                for (int i = 0; i < SORT_WAVES; ++i) { c[j][i] = cnt[i][d]; tot += c[j][i]; }
+                gt[j] = digit_total[d];
+                gsum += gt[j];
+            }
+        }
+        uint32_t unused;
+        uint32_t dbase = block_excl_scan(tot, wave_sums, &unused);      // first slot of the lane's first digit in the tile
+        uint32_t gbase = block_excl_scan(gsum, wave_sums, &unused);     // first position of that digit in the whole output
+#pragma unroll
+        for (int j = 0; j < DPT; ++j) {
+            const int d = threadIdx.x * DPT + j;
+            if (d < BINS) {
+                gofs[d] = gbase + prefix[(size_t)d * nblk + blockIdx.x] - dbase;
+                uint32_t run = dbase;
+#pragma unroll
+                for (int i = 0; i < SORT_WAVES; ++i) { cnt[i][d] = run; run += c[j][i]; }
+                dbase = run;
+                gbase += gt[j];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        if (wbase + r * 64 + lane < n) {
+            const uint32_t d = (k[r] >> shift) & dmask;
+            ordered[cnt[w][d] + rank[r]] = make_uint2(k[r], v[r]);
+        }
+    }
+    __syncthreads();
+    const uint32_t nvalid = n - tile0 < (uint32_t)TILE ? n - tile0 : (uint32_t)TILE;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const uint32_t i = j * 256 + threadIdx.x;
+        if (i < nvalid) {
+            const uint2 kv = ordered[i];
+            const uint32_t p = gofs[(kv.x >> shift) & dmask] + i;
+            kout[p] = kv.x;
+            vout[p] = kv.y;
+        }
+    }
+}
+
+constexpr int SORT_ITEMS = TF_SORT_ITEMS;        // pairs per lane: tiles of 256 * SORT_ITEMS pairs
+constexpr int SORT_TILE = 256 * SORT_ITEMS;
+constexpr int SORT_RB_MAX = TF_SORT_RB_MAX;      // widest digit
+
+struct SortPlan {
+    int passes, rb;
+    uint32_t nblk;
+    size_t counts_bytes, total_bytes, tmp_bytes;
+};
+
+SortPlan sort_plan(size_t n, int end_bit)
+{
+    SortPlan p;
+    if (end_bit < 1) end_bit = 1;
+    p.passes = (end_bit + SORT_RB_MAX - 1) / SORT_RB_MAX;
+    p.rb = (end_bit + p.passes - 1) / p.passes;
+    if (p.rb < 6) p.rb = 6;
+    p.nblk = (uint32_t)((n + SORT_TILE - 1) / SORT_TILE);
+    if (p.nblk == 0) p.nblk = 1;
+    p.counts_bytes = tf_align(sizeof(uint32_t) * ((size_t)1 << p.rb) * p.nblk);
+    p.total_bytes = tf_align(sizeof(uint32_t) * ((size_t)1 << p.rb));
+    p.tmp_bytes = p.passes > 1 ? tf_align(sizeof(uint32_t) * n) : 0;
+    return p;
+}
+
+template <int RB>
+int sort_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, uint32_t n, int shift, uint32_t dmask,
+              uint32_t *counts, uint32_t *totals, uint32_t nblk, hipStream_t stream)
+{
+    sort_hist_kernel<RB, SORT_ITEMS><<<nblk, 256, 0, stream>>>(kin, n, shift, dmask, counts, nblk);
+    sort_scan_kernel<<<1 << RB, 256, 0, stream>>>(counts, nblk, totals);
+    sort_scatter_kernel<RB, SORT_ITEMS><<<nblk, 256, 0, stream>>>(kin, vin, kout, vout, n, shift, dmask, counts, totals, nblk);
+    TF_HIP(hipGetLastError());
+    return TFREC_OK;
+}
+
+}  // namespace
 
 size_t tfrec_sort_temp_bytes(size_t n, int end_bit)
 {
-    size_t bytes = 0;
-    uint32_t *k = nullptr, *v = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, n, 0, (unsigned)end_bit, (hipStream_t) nullptr);
-    return bytes ? bytes : 256;
+    const SortPlan p = sort_plan(n, end_bit);
+    return p.counts_bytes + p.total_bytes + 2 * p.tmp_bytes + 256;
 }
 
 int tfrec_sort_pairs(void *d_temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
                      const uint32_t *vals_in, uint32_t *vals_out, size_t n, int end_bit, hipStream_t stream)
 {
-    hipError_t e = rocprim::radix_sort_pairs(d_temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0,
-                                             (unsigned)end_bit, stream);
-    if (e != hipSuccess) {
-        tfrec_set_error("radix_sort_pairs failed: %s", hipGetErrorString(e));
-        return TFREC_EHIP;
+    if (n == 0) return TFREC_OK;
+    TF_REQUIRE(n < (1ull << 32), TFREC_EUNSUP, "sort of %zu pairs: positions must fit 32 bits", n);
+    TF_REQUIRE(end_bit >= 1 && end_bit <= 32, TFREC_EINVAL, "sort key width %d out of range", end_bit);
+    const SortPlan p = sort_plan(n, end_bit);
+    TF_REQUIRE(temp_bytes >= p.counts_bytes + p.total_bytes + 2 * p.tmp_bytes, TFREC_EINVAL, "internal: sort scratch too small");
+    char *t = (char *)d_temp;
+    uint32_t *counts = (uint32_t *)t; t += p.counts_bytes;
+    uint32_t *totals = (uint32_t *)t; t += p.total_bytes;
+    uint32_t *ktmp = (uint32_t *)t; t += p.tmp_bytes;
+    uint32_t *vtmp = (uint32_t *)t;
+    // the last pass writes the output arrays; the passes before it alternate backwards from there
+    const uint32_t *kin = keys_in, *vin = vals_in;
+    for (int pass = 0; pass < p.passes; ++pass) {
+        const bool to_out = ((p.passes - 1 - pass) & 1) == 0;
+        uint32_t *ko = to_out ? keys_out : ktmp, *vo = to_out ? vals_out : vtmp;
+        const int shift = pass * p.rb;
+        const int bits = end_bit - shift < p.rb ? end_bit - shift : p.rb;
+        const uint32_t dmask = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+        int rc = TFREC_EUNSUP;
+        switch (p.rb) {
+            case 6: rc = sort_pass<6>(kin, vin, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream); break;
+            case 7: rc = sort_pass<7>(kin, vin, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream); break;
+            case 8: rc = sort_pass<8>(kin, vin, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream); break;
+            case 9: rc = sort_pass<9>(kin, vin, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream); break;
+            case 10: rc = sort_pass<10>(kin, vin, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream); break;
+            case 11: rc = sort_pass<11>(kin, vin, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream); break;
+            default: tfrec_set_error("internal: no sort kernel for %d-bit digits", p.rb);
+        }
+        if (rc != TFREC_OK) return rc;
+        kin = ko; vin = vo;
     }
     return TFREC_OK;
+}
+
+extern "C" int tfrec_sort_pairs_u32(tfrec_ctx *ctx, const uint32_t *d_keys_in, const uint32_t *d_vals_in, uint32_t *d_keys_out,
+                                    uint32_t *d_vals_out, int64_t n, int key_bits)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_REQUIRE(n >= 0 && n < (1ll << 32), TFREC_EINVAL, "pair count %lld out of range", (long long)n);
+    TF_REQUIRE(key_bits >= 1 && key_bits <= 32, TFREC_EINVAL, "key width %d out of range", key_bits);
+    if (n == 0) return TFREC_OK;
+    TF_REQUIRE(d_keys_in && d_vals_in && d_keys_out && d_vals_out, TFREC_EINVAL, "null array");
+    TF_REQUIRE(d_keys_in != d_keys_out && d_vals_in != d_vals_out, TFREC_EINVAL, "the sort is not in place");
+    const size_t bytes = tfrec_sort_temp_bytes((size_t)n, key_bits);
+    TF_TRY(tfrec_ws_require(ctx, ctx->ws_used + tf_align(bytes)));
+    void *tmp = tfrec_ws_take(ctx, bytes);
+    TF_REQUIRE(tmp != nullptr, TFREC_ENOMEM, "internal: workspace carve failed");
+    return tfrec_sort_pairs(tmp, bytes, d_keys_in, d_keys_out, d_vals_in, d_vals_out, (size_t)n, key_bits, ctx->stream);
 }

@@ -174,6 +174,14 @@ class Device:
         _lib.check(self.lib.tfrec_mf_predict(self.h, _ptr(P), _ptr(Q), _ptr(b), U, I, d, _ptr(users), _ptr(items), n, _ptr(out)))
         return out
 
+    def sort_pairs(self, keys, vals, key_bits, out_keys=None, out_vals=None):
+        """Stable sort of uint32 (key, value) pairs by the low ``key_bits`` bits of the key."""
+        n = _shape(keys)[0]
+        out_keys = out_keys if out_keys is not None else self.empty(n, np.uint32)
+        out_vals = out_vals if out_vals is not None else self.empty(n, np.uint32)
+        _lib.check(self.lib.tfrec_sort_pairs_u32(self.h, _ptr(keys), _ptr(vals), _ptr(out_keys), _ptr(out_vals), n, int(key_bits)))
+        return out_keys, out_vals
+
     def bpr_sgd_step(self, P, Q, b, users, pos, neg, lr, reg, loss=None):
         """One minibatch step (model/BPR.py:36-48 + :72).  ``loss``: optional device float64[2]."""
         U, d = _shape(P)
