@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--prep-batches", type=int, default=1, help="batches sorted per index preparation (single GPU)")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU code path even on one GPU (testing)")
+    ap.add_argument("--item-mode", default="auto", choices=["auto", "dense", "sharded"],
+                    help="multi-GPU item table: replicated with one all-reduce of gradient sums per step, or sharded with all-to-all lookups")
     ap.add_argument("--extras", action="store_true", help="also time the reference batch size (512 triples per step)")
     args = ap.parse_args()
 
@@ -151,15 +153,30 @@ def main():
             trainer = None
         else:
             from tfrec_amd.sharded import ShardedBprTrainer
-            trainer = ShardedBprTrainer(dev, U, I, d, lr, reg, seed=2018, device=cuda)
+            trainer = ShardedBprTrainer(dev, U, I, d, lr, reg, seed=2018, device=cuda, item_mode=args.item_mode)
             lo, hi = trainer.user_range
             users = (torch.randint(0, hi - lo, (n_batches * B,), device=cuda, generator=gen, dtype=torch.int32) + lo)
             pos = zipf_items(I, n_batches * B, gen, cuda)
             neg = torch.randint(0, I, (n_batches * B,), device=cuda, generator=gen, dtype=torch.int32)
 
-            def step(s):
+            def batch(s):
                 o = (s % n_batches) * B
-                trainer.step(users[o:o + B], pos[o:o + B], neg[o:o + B])
+                return users[o:o + B], pos[o:o + B], neg[o:o + B]
+
+            if trainer.item_mode == "dense":
+                # replicated item table: the index work of the next batch runs on the auxiliary stream
+                # beside this step's row passes, all-reduce and update
+                state = {"next": 0}
+                trainer.prepare(0, *batch(0))
+
+                def step(s):
+                    k = state["next"]
+                    trainer.prepare((k + 1) & 1, *batch(k + 1))
+                    trainer.step_prepared(k & 1)
+                    state["next"] = k + 1
+            else:
+                def step(s):
+                    trainer.step(*batch(s))
 
         def barrier():
             if world > 1:
@@ -195,9 +212,17 @@ def main():
                                    "users uniform, positives Zipf(1.0), negatives uniform" % (U // 10**6, I // 1000, d, B),
                        "users": U, "items": I, "factors": d, "batch_per_gpu": B, "global_batch": B * world,
                        "lr": lr, "reg": reg, "resident_batches": n_batches,
-                       "parallelism": "single GPU" if world == 1 else "tables row-sharded over %d GPUs, all-to-all per step" % world},
+                       "parallelism": "single GPU" if trainer is None else (
+                           "user table row-sharded over %d GPUs, item table replicated, one all-reduce of item gradient sums per step" % world
+                           if trainer.item_mode == "dense" else "tables row-sharded over %d GPUs, all-to-all lookups per step" % world)},
         }
 
+        if trainer is not None:
+            # multi-GPU path: per-GPU algorithmic rate over the whole step (exchange included)
+            per_gpu = B * alg_bytes_per_triple / (wall / args.steps) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": per_gpu, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per_gpu / HBM_PEAK_GBS,
+                               "traffic": None, "kernel": "per GPU: one BPR step incl. the item-gradient exchange",
+                               "algorithmic_bytes_per_triple": alg_bytes_per_triple}
         if rank == 0 and world == 1 and not args.force_sharded:
             # ---- roofline of the step's kernels: HIP events recorded by the library on its own stream
             # (un-pipelined steps, so that the index phase is timed on the same stream as the row passes)

@@ -148,6 +148,21 @@ int tfrec_bpr_grad_step(tfrec_ctx *ctx, float *d_P, float *d_Qc, float *d_bc,
 int tfrec_rows_sgd_apply(tfrec_ctx *ctx, float *d_Q, float *d_b, int64_t I, int d,
                          const int32_t *d_ids, const float *d_grad_rows, const float *d_grad_b, int64_t n, float lr);
 
+/* The step of a GPU that holds a shard of P and a full copy of Q, b (small item tables): P is
+ * updated in place; d_G = [I*d | I] floats is zeroed and receives, for every item the batch
+ * touches, the summed gradient of its row and bias (regularisation included).  The caller sums
+ * d_G over the GPUs (all-reduce) and applies tfrec_axpy(Qb, G, -lr) to every copy: together that
+ * is sess.run(self.update) of model/BPR.py:72 on the union of the GPUs' batches.
+ * slot -1 sorts the given index arrays now; slot 0/1 consumes a batch prepared with
+ * tfrec_batch_prepare (the index arrays are then ignored and may be null). */
+int tfrec_bpr_dense_grad_step(tfrec_ctx *ctx, int slot, float *d_P, const float *d_Q, const float *d_b, float *d_G,
+                              int64_t U, int64_t I, int d,
+                              const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg, int64_t B,
+                              float lr, float reg, double *d_loss);
+/* y[i] = fma(alpha, x[i], y[i]) for i < n: the plain SGD update (model/BPR.py:48) of a replicated
+ * table from a summed gradient table, alpha = -learning rate. */
+int tfrec_axpy(tfrec_ctx *ctx, float *d_y, const float *d_x, float alpha, int64_t n);
+
 /* One APR minibatch step: both session calls of model/APR.py:163-164.
  *   1) delta <- eps * l2_normalize(d L_bpr / d Theta)   (model/APR.py:116-132; rows one by one,
  *      the bias gradient as one vector over all items)

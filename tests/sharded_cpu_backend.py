@@ -31,6 +31,24 @@ class CpuBackend:
         Q_[:] = gQ.astype(np.float32)
         b_[:] = gb.astype(np.float32)
 
+    def bpr_dense_grad_step(self, P, Q, b, G, users, pos, neg, lr, reg, slot=-1):
+        assert slot == -1, "the CPU stand-in has no prepared batches"
+        I, d = Q.shape
+        Qc, bc = Q.clone(), b.clone()
+        G.zero_()
+        if users.shape[0] == 0:
+            return
+        self.bpr_grad_step(P, Qc, bc, users, pos, neg, lr, reg)
+        touched = torch.zeros(I, dtype=torch.bool)
+        touched[pos.to(torch.int64)] = True
+        touched[neg.to(torch.int64)] = True
+        G[: I * d].view(I, d)[touched] = Qc[touched]
+        G[I * d:][touched] = bc[touched]
+
+    def axpy(self, y, x, alpha):
+        y_, x_ = _np(y), _np(x)
+        y_[:] = (y_.astype(np.float64) + alpha * x_.astype(np.float64)).astype(np.float32)
+
     def rows_sgd_apply(self, Q, b, ids, grad_rows, grad_b, lr):
         Q_, b_ = _np(Q), _np(b)
         g = np.zeros(Q_.shape); gb = np.zeros(b_.shape)

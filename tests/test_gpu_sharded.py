@@ -8,25 +8,36 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_single_rank_sharded_path_matches_unsharded(oracle):
+@pytest.mark.parametrize("item_mode", ["sharded", "dense"])
+def test_single_rank_sharded_path_matches_unsharded(oracle, item_mode):
     from tfrec_amd.sharded import ShardedBprTrainer, ShardedEvaluator, make_device
     dev = make_device(0)
     cuda = torch.device("cuda", 0)
     U, I, d, B, k = 5000, 3000, 64, 40000, 50
-    tr = ShardedBprTrainer(dev, U, I, d, 0.01, 0.05, seed=2018)
+    tr = ShardedBprTrainer(dev, U, I, d, 0.01, 0.05, seed=2018, item_mode=item_mode)
     P0, Q0, b0 = [x.clone() for x in (tr.P, tr.Q, tr.b)]
     rng = np.random.default_rng(0)
     batches = [[torch.from_numpy(rng.integers(0, n, B).astype(np.int32)).to(cuda) for n in (U, I, I)] for _ in range(3)]
     for u, i, j in batches:
         tr.step(u, i, j)
+    if item_mode == "dense":
+        # and once more with the index work prepared ahead on the auxiliary stream
+        tr.prepare(0, *batches[0])
+        tr.prepare(1, *batches[1])
+        tr.step_prepared(0)
+        tr.step_prepared(1)
+        batches = batches + batches[:2]
     for u, i, j in batches:
         dev.bpr_sgd_step(P0, Q0, b0, u, i, j, 0.01, 0.05)
     dev.synchronize()
     for a, c in ((tr.P, P0), (tr.Q, Q0), (tr.b, b0)):
-        np.testing.assert_allclose(a.cpu().numpy(), c.cpu().numpy(), rtol=1e-5, atol=1e-7)
+        if item_mode == "dense":     # same arithmetic in the same order on one rank: the same bits
+            assert np.array_equal(a.cpu().numpy(), c.cpu().numpy())
+        else:
+            np.testing.assert_allclose(a.cpu().numpy(), c.cpu().numpy(), rtol=1e-5, atol=1e-7)
     # the shard initialiser reproduces the whole-table stream
     whole = dev.uniform((U, d), -0.05, 0.05, 2018 * 2 + 1).numpy()
-    part = ShardedBprTrainer(dev, U, I, d, 0.01, 0.05, seed=2018)
+    part = ShardedBprTrainer(dev, U, I, d, 0.01, 0.05, seed=2018, item_mode=item_mode)
     assert np.array_equal(part.P.cpu().numpy(), whole)
 
     deg = 12

@@ -49,6 +49,8 @@ SIGNATURES = {
     "tfrec_bpr_sgd_step_prepared": (_int, [_p, _int, _p, _p, _p, _i64, _i64, _int, _f, _f, _p]),
     "tfrec_bpr_grad_step": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _i64, _f, _f, _p]),
     "tfrec_rows_sgd_apply": (_int, [_p, _p, _p, _i64, _int, _p, _p, _p, _i64, _f]),
+    "tfrec_bpr_dense_grad_step": (_int, [_p, _int, _p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _i64, _f, _f, _p]),
+    "tfrec_axpy": (_int, [_p, _p, _p, _f, _i64]),
     "tfrec_apr_adagrad_step": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _i64,
                                       _f, _f, _f, _f, _p]),
     "tfrec_dns_select": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _i64, _int, _p]),

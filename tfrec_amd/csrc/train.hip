@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void build_keys_kernel(const int32_t *__restri
 
 struct BprParams {
     float *P, *Q, *b;
+    float *gQ, *gb;      // where the item pass leaves gradient sums when it does not apply them (may alias Q, b)
     float *stage;        // [B, d] pre-step P[u] of every triple
     float *sbuf;         // [B]    s = sigma(-(x + 1e-7)) of every triple
     const uint2 *pair;   // [B]    (i, j) of every triple, range-checked
@@ -126,8 +127,9 @@ struct BprUserPol {
 };
 
 // GRAD = false: apply the SGD update to Q, b.  GRAD = true: leave the summed gradient of every
-// distinct item in its Q row and b entry instead (the tables then hold fetched copies of rows
-// owned by other GPUs, and the sums travel back to the owners).
+// distinct item in row `it` of gQ / entry `it` of gb instead.  Those are either Q, b themselves
+// (the tables then hold fetched copies of rows owned by other GPUs, and the sums travel back to
+// the owners) or a zeroed table of the shape of Q, b that is then summed over the GPUs.
 template <int LPR_, int NCH_, int VEC_, bool FULL_, bool GRAD = false>
 struct BprItemPol {
     enum { LPR = LPR_, NCH = NCH_, VEC = VEC_, DEPTH = TF_DEPTH_ITEM };
@@ -168,8 +170,8 @@ struct BprItemPol {
         const float nreg = (float)acc.cnt * a.reg, lr = a.lr;
         if constexpr (GRAD) {
             const RowT out = q.map2(acc.v, [=](float qv, float av) { return fmaf(nreg, qv, -av); });
-            out.store(row, gl, DM::nchunk(a.nchunk));
-            if (gl == 0) a.b[it] = fmaf(nreg, bk, -acc.s0);
+            out.store(a.gQ + (size_t)it * DM::d(a.d), gl, DM::nchunk(a.nchunk));
+            if (gl == 0) a.gb[it] = fmaf(nreg, bk, -acc.s0);
         } else {
             const RowT out = q.map2(acc.v, [=](float qv, float av) { return fmaf(-lr, fmaf(nreg, qv, -av), qv); });
             out.store(row, gl, DM::nchunk(a.nchunk));
@@ -721,7 +723,7 @@ static int run_pass(tfrec_ctx *ctx, const Pol &pol, const StepWs &w, const uint3
 
 // the row passes of one BPR step over an already sorted batch
 static int bpr_passes(tfrec_ctx *ctx, const tfrec_batch_slot &sl, float *d_P, float *d_Q, float *d_b, int64_t U, int d,
-                      float lr, float reg, double *d_loss, bool item_grad_only = false)
+                      float lr, float reg, double *d_loss, bool item_grad_only = false, float *d_gQ = nullptr, float *d_gb = nullptr)
 {
     const int64_t B = sl.B;
     const int64_t k0 = sl.next_k;                 // which of the slot's batches this step consumes
@@ -730,7 +732,7 @@ static int bpr_passes(tfrec_ctx *ctx, const tfrec_batch_slot &sl, float *d_P, fl
     TF_REQUIRE(pick_cfg(d, all_aligned16({d_P, d_Q}), &cfg), TFREC_EUNSUP, "factor size d=%d is not supported (max 256)", d);
     StepWs w;
     TF_TRY(step_ws_carve(ctx, B, d, cfg, &w));
-    BprParams a{d_P, d_Q, d_b, w.stage, w.sbuf, sl.pair + B * k0, (uint32_t)U, d, d / cfg.vec, lr, reg, sl.kmask};
+    BprParams a{d_P, d_Q, d_b, d_gQ ? d_gQ : d_Q, d_gb ? d_gb : d_b, w.stage, w.sbuf, sl.pair + B * k0, (uint32_t)U, d, d / cfg.vec, lr, reg, sl.kmask};
     const bool want_loss = d_loss != nullptr;
     return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC, bool FULL>() -> int {
         if (want_loss) {
@@ -880,6 +882,75 @@ extern "C" int tfrec_bpr_sgd_step_prepared(tfrec_ctx *ctx, int slot, float *d_P,
         sl.B = -1;
     }
     return rc;
+}
+
+// The step for a GPU that holds a shard of P and a full copy of Q, b: P is updated in place; the
+// item side leaves, in the zeroed table G = [I*d gradient rows | I bias gradients], the gradient sum
+// (regularisation term included) of every item this batch touches.  Summing G over the GPUs and
+// applying Q -= lr*G on every copy is the unsharded step.
+extern "C" int tfrec_bpr_dense_grad_step(tfrec_ctx *ctx, int slot, float *d_P, const float *d_Q, const float *d_b, float *d_G,
+                                         int64_t U, int64_t I, int d, const int32_t *d_users, const int32_t *d_pos,
+                                         const int32_t *d_neg, int64_t B, float lr, float reg, double *d_loss)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_REQUIRE(slot >= -1 && slot <= 1, TFREC_EINVAL, "slot must be -1 (sort now), 0 or 1");
+    TF_REQUIRE(d_G != nullptr && ((uintptr_t)d_G & 15u) == 0, TFREC_EINVAL, "gradient table missing or not 16-byte aligned");
+    if (slot < 0) TF_TRY(check_step_args(d_P, d_Q, d_b, U, I, d, d_users, d_pos, d_neg, B));
+    else TF_TRY(check_step_args(d_P, d_Q, d_b, U, I, d, d_P, d_P, d_P, 1));
+    TF_HIP(hipMemsetAsync(d_G, 0, sizeof(float) * ((size_t)I * d + (size_t)I), ctx->stream));
+    tfrec_marks_reset(ctx);
+    tfrec_mark(ctx, "start");
+    float *gQ = d_G, *gb = d_G + (size_t)I * d;
+    if (slot < 0) {
+        if (B == 0) {
+            if (d_loss) TF_HIP(hipMemsetAsync(d_loss, 0, 2 * sizeof(double), ctx->stream));
+            return TFREC_OK;
+        }
+        tfrec_batch_slot &sl = ctx->slots[2];
+        TF_TRY(slot_prepare(ctx, sl, ctx->stream, d_users, d_pos, d_neg, B, U, I));
+        tfrec_mark(ctx, "index");
+        return bpr_passes(ctx, sl, d_P, const_cast<float *>(d_Q), const_cast<float *>(d_b), U, d, lr, reg, d_loss, true, gQ, gb);
+    }
+    tfrec_batch_slot &sl = ctx->slots[slot];
+    TF_REQUIRE(sl.B >= 1, TFREC_EINVAL, "slot %d holds no prepared batch", slot);
+    TF_REQUIRE(sl.U == U && sl.I == I, TFREC_EINVAL, "slot %d was prepared for a %lldx%lld model", slot, (long long)sl.U, (long long)sl.I);
+    TF_HIP(hipStreamWaitEvent(ctx->stream, sl.ready, 0));
+    const int rc = bpr_passes(ctx, sl, d_P, const_cast<float *>(d_Q), const_cast<float *>(d_b), U, d, lr, reg, d_loss, true, gQ, gb);
+    if (++sl.next_k >= sl.K) {
+        TF_HIP(hipEventRecord(sl.released, ctx->stream));
+        sl.has_released = true;
+        sl.B = -1;
+    }
+    return rc;
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(float *__restrict__ y, const float *__restrict__ x, float alpha, int64_t n4, int64_t n)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < n4) {
+        float4 a = reinterpret_cast<float4 *>(y)[t];
+        const float4 g = reinterpret_cast<const float4 *>(x)[t];
+        a.x = fmaf(alpha, g.x, a.x); a.y = fmaf(alpha, g.y, a.y); a.z = fmaf(alpha, g.z, a.z); a.w = fmaf(alpha, g.w, a.w);
+        reinterpret_cast<float4 *>(y)[t] = a;
+    } else {
+        const int64_t i = n4 * 4 + (t - n4);
+        if (i < n) y[i] = fmaf(alpha, x[i], y[i]);
+    }
+}
+
+// y[i] = fma(alpha, x[i], y[i]): with alpha = -lr and x the summed gradient table this is the SGD update
+// of model/BPR.py:48 on a replicated table.
+extern "C" int tfrec_axpy(tfrec_ctx *ctx, float *d_y, const float *d_x, float alpha, int64_t n)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_REQUIRE(n >= 0, TFREC_EINVAL, "negative length");
+    if (n == 0) return TFREC_OK;
+    TF_REQUIRE(d_y && d_x, TFREC_EINVAL, "null array");
+    const bool vec = (((uintptr_t)d_y | (uintptr_t)d_x) & 15u) == 0;
+    const int64_t n4 = vec ? n / 4 : 0, threads = n4 + (n - 4 * n4);
+    axpy_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, ctx->stream>>>(d_y, d_x, alpha, n4, n);
+    TF_HIP(hipGetLastError());
+    return TFREC_OK;
 }
 
 extern "C" int tfrec_apr_adagrad_step(tfrec_ctx *ctx, float *d_P, float *d_Q, float *d_b, float *d_accP, float *d_accQ,

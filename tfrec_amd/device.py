@@ -216,6 +216,21 @@ class Device:
         _lib.check(self.lib.tfrec_bpr_grad_step(self.h, _ptr(P), _ptr(Qc), _ptr(bc), U, Ic, d, _ptr(users), _ptr(pos_slot),
                                                 _ptr(neg_slot), B, float(lr), float(reg), _ptr(loss)))
 
+    def bpr_dense_grad_step(self, P, Q, b, G, users, pos, neg, lr, reg, slot=-1, loss=None):
+        """Step of a GPU holding a P shard and a full Q, b copy: P updated in place, the flat table
+        ``G`` ([I*d | I] floats) zeroed and filled with the gradient sums of the touched items.
+        ``slot`` 0/1 consumes a batch prepared with ``prepare_batch`` (index arrays may be None)."""
+        U, d = _shape(P)
+        I = _shape(Q)[0]
+        B = _shape(users)[0] if users is not None else 0
+        _lib.check(self.lib.tfrec_bpr_dense_grad_step(self.h, int(slot), _ptr(P), _ptr(Q), _ptr(b), _ptr(G), U, I, d, _ptr(users),
+                                                      _ptr(pos), _ptr(neg), B, float(lr), float(reg), _ptr(loss)))
+
+    def axpy(self, y, x, alpha, n=None):
+        """y[i] = fma(alpha, x[i], y[i])."""
+        n = int(n) if n is not None else int(np.prod(_shape(y)))
+        _lib.check(self.lib.tfrec_axpy(self.h, _ptr(y), _ptr(x), float(alpha), n))
+
     def rows_sgd_apply(self, Q, b, ids, grad_rows, grad_b, lr):
         """Sharded step, owner side: Q[ids] -= lr * grad_rows (duplicates summed in order), b likewise."""
         I, d = _shape(Q)

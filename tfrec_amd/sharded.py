@@ -13,6 +13,12 @@ Layout
     fetched copies, which leaves one summed gradient per distinct item, (5) all-to-all: returns
     those sums, (6) owners add the sums of all ranks in rank order and apply the SGD update.
     Wire traffic per triple is at most two item rows each way, less after deduplication.
+  * small item tables ("dense" mode, chosen automatically below DENSE_ITEM_BYTES): every rank keeps
+    a full copy of Q and b instead.  A step then needs no lookups: each rank runs its local step,
+    which updates its P shard and leaves the gradient sums of the items it touched in a zeroed table
+    of the shape of [Q | b]; one all-reduce sums the tables; every rank applies the same update to
+    its copy.  No host synchronisation, one collective per step.  For evaluation each rank scores
+    its own item range of the copy, as in the sharded layout.
   * evaluation: item-sharded.  The factor rows of a chunk of evaluated users are broadcast from
     their owner, every rank takes the top-k over its own items (global ids), the lists are
     all-gathered and merged under the total order (score desc, id asc) -- so the result is that
@@ -25,6 +31,9 @@ run the exchange logic under gloo without a GPU; this module never falls back by
 import numpy as np
 import torch
 import torch.distributed as dist
+
+
+DENSE_ITEM_BYTES = 256 << 20     # item tables up to this size are replicated rather than sharded
 
 
 def _part(n, world):
@@ -43,6 +52,15 @@ class HipBackend:
 
     def rows_sgd_apply(self, Q, b, ids, grad_rows, grad_b, lr):
         self.dev.rows_sgd_apply(Q, b, ids, grad_rows, grad_b, lr)
+
+    def bpr_dense_grad_step(self, P, Q, b, G, users, pos, neg, lr, reg, slot=-1):
+        self.dev.bpr_dense_grad_step(P, Q, b, G, users, pos, neg, lr, reg, slot=slot)
+
+    def prepare_batch(self, slot, U, I, users, pos, neg):
+        self.dev.prepare_batch(slot, U, I, users, pos, neg)
+
+    def axpy(self, y, x, alpha):
+        self.dev.axpy(y, x, alpha)
 
     def score_topk_shard(self, P_rows, Q, b, item_lo, users, k, train, mode):
         n = P_rows.shape[0]
@@ -93,7 +111,7 @@ class ShardedBprTrainer:
     """BPR-MF with row-sharded tables.  ``step`` takes this rank's triples: global ids, every user
     inside ``user_range``."""
 
-    def __init__(self, dev_or_backend, U, I, d, lr, reg, seed=2018, device=None, group=None):
+    def __init__(self, dev_or_backend, U, I, d, lr, reg, seed=2018, device=None, group=None, item_mode="auto"):
         self.backend = dev_or_backend if hasattr(dev_or_backend, "uniform_rows") else HipBackend(dev_or_backend)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -105,12 +123,28 @@ class ShardedBprTrainer:
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         self.device = device
+        if item_mode == "auto":
+            item_mode = "dense" if 4 * self.I * (self.d + 1) <= DENSE_ITEM_BYTES else "sharded"
+        if item_mode not in ("dense", "sharded"):
+            raise ValueError("item_mode must be 'auto', 'dense' or 'sharded'")
+        self.item_mode = item_mode
         nu, ni = self.user_range[1] - self.user_range[0], self.item_range[1] - self.item_range[0]
         # model/base/MatrixFactorization.py:17-21; the stream of random numbers is that of the unsharded
         # table, so the shards of any world size assemble into the same initial model
         self.P = self._init_rows(self.U, self.user_range, seed * 2 + 1)
-        self.Q = self._init_rows(self.I, self.item_range, seed * 2 + 2)
-        self.b = torch.zeros(max(ni, 1), dtype=torch.float32, device=device)[:ni]
+        if item_mode == "dense":
+            # [Q | b] in one flat buffer, so that one all-reduce and one update cover both
+            self._Qb = torch.zeros(self.I * (self.d + 1), dtype=torch.float32, device=device)
+            self._Qb[: self.I * self.d].view(self.I, self.d).copy_(self._init_rows(self.I, (0, self.I), seed * 2 + 2))
+            self._G = torch.zeros_like(self._Qb)
+            self.Q_full = self._Qb[: self.I * self.d].view(self.I, self.d)
+            self.b_full = self._Qb[self.I * self.d:]
+            # the views the item-sharded evaluator works on: this rank's item range of the copy
+            self.Q = self.Q_full[self.item_range[0]:self.item_range[1]]
+            self.b = self.b_full[self.item_range[0]:self.item_range[1]]
+        else:
+            self.Q = self._init_rows(self.I, self.item_range, seed * 2 + 2)
+            self.b = torch.zeros(max(ni, 1), dtype=torch.float32, device=device)[:ni]
         assert self.P.shape[0] == nu and self.Q.shape[0] == ni
         self._mark = None
 
@@ -127,8 +161,29 @@ class ShardedBprTrainer:
         dist.all_to_all_single(out, send.contiguous(), list(recv_counts), list(send_counts), group=self.group)
         return out
 
+    def prepare(self, slot, users, pos, neg):
+        """Dense mode: sorts the index arrays of an upcoming batch on the library's auxiliary stream
+        (slot 0 or 1), beside whatever the main stream is doing; ``step_prepared(slot)`` consumes it."""
+        assert self.item_mode == "dense"
+        self.backend.prepare_batch(slot, self.user_range[1] - self.user_range[0], self.I,
+                                   (users.to(torch.int32) - self.user_range[0]).contiguous(), pos.contiguous(), neg.contiguous())
+
+    def step_prepared(self, slot):
+        self._dense_step(None, None, None, slot)
+
+    def _dense_step(self, users, pos, neg, slot):
+        if users is not None:
+            users = (users.to(torch.int32) - self.user_range[0]).contiguous()
+            pos, neg = pos.to(torch.int32).contiguous(), neg.to(torch.int32).contiguous()
+        self.backend.bpr_dense_grad_step(self.P, self.Q_full, self.b_full, self._G, users, pos, neg, self.lr, self.reg, slot=slot)
+        if self.world > 1:
+            dist.all_reduce(self._G, group=self.group)
+        self.backend.axpy(self._Qb, self._G, -self.lr)
+
     def step(self, users, pos, neg):
         """One global minibatch step; collective: every rank must call it (an empty batch is allowed)."""
+        if self.item_mode == "dense":
+            return self._dense_step(users, pos, neg, -1)
         dev, W = self.device, self.world
         users = users.to(torch.int32)
         B = users.shape[0]
@@ -183,6 +238,8 @@ class ShardedBprTrainer:
             outs = [torch.empty_like(pad) for _ in range(self.world)]
             dist.all_gather(outs, pad, group=self.group)
             return torch.cat(outs)[:n]
+        if self.item_mode == "dense":
+            return cat(self.P, self.U), self.Q_full.clone(), self.b_full.clone()
         return cat(self.P, self.U), cat(self.Q, self.I), cat(self.b, self.I)
 
 
