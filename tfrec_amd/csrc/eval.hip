@@ -56,6 +56,13 @@ __device__ __forceinline__ bool csr_row_contains(const int32_t *__restrict__ idx
     return false;
 }
 
+// The value the lane 32 places away holds (v_permlane32_swap: a vector-ALU move, no LDS trip).
+__device__ __forceinline__ uint32_t swap32(uint32_t x, int lane)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return (lane & 32) ? r[0] : r[1];
+}
+
 // Wave-wide bitonic sort of CAP 64-bit keys in LDS, descending.  All 64 lanes must call it.
 template <int CAP>
 __device__ __forceinline__ void wave_sort_desc(volatile uint64_t *buf, int lane)
@@ -77,27 +84,121 @@ __device__ __forceinline__ void wave_sort_desc(volatile uint64_t *buf, int lane)
     }
 }
 
+// Lane exchange of a 32-bit word with the lane whose number differs in bit J (J = 1..32).
+template <int J>
+__device__ __forceinline__ uint32_t xor_lane_u32(uint32_t v, int lane)
+{
+    if constexpr (J == 32) return swap32(v, lane);
+    else if constexpr (J == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    else return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (J << 10) | 0x1f);                           // bit-mask mode, xor J
+}
+
+// Wave-wide bitonic sort, descending, of CAP 64-bit keys held EPL = CAP/64 per lane: key[q] of lane
+// l is element q*64 + l.  Partners 64 or more elements apart sit in the same lane (register
+// compare-exchange); nearer partners are fetched with cross-lane moves, no LDS round trips.
+template <int CAP, int K2, int J>
+__device__ __forceinline__ void bitonic_step(uint64_t (&key)[CAP / 64], int lane)
+{
+    constexpr int EPL = CAP / 64;
+    if constexpr (J >= 64) {
+        constexpr int JQ = J / 64;
+#pragma unroll
+        for (int q = 0; q < EPL; ++q) {
+            if ((q & JQ) == 0) {
+                const bool desc = (((q * 64 + lane) & K2) == 0);
+                const uint64_t x = key[q], y = key[q | JQ];
+                const bool swap = desc ? (x < y) : (x > y);
+                key[q] = swap ? y : x;
+                key[q | JQ] = swap ? x : y;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < EPL; ++q) {
+            const uint64_t x = key[q];
+            const uint32_t plo = xor_lane_u32<J>((uint32_t)x, lane), phi = xor_lane_u32<J>((uint32_t)(x >> 32), lane);
+            const uint64_t y = ((uint64_t)phi << 32) | plo;
+            const bool desc = (((q * 64 + lane) & K2) == 0);
+            const bool lower = (lane & J) == 0;
+            const bool take_max = (lower == desc);
+            key[q] = take_max ? (x > y ? x : y) : (x < y ? x : y);
+        }
+    }
+}
+template <int CAP, int K2, int J>
+__device__ __forceinline__ void bitonic_merge(uint64_t (&key)[CAP / 64], int lane)
+{
+    bitonic_step<CAP, K2, J>(key, lane);
+    if constexpr (J > 1) bitonic_merge<CAP, K2, J / 2>(key, lane);
+}
+template <int CAP, int K2>
+__device__ __forceinline__ void bitonic_sort(uint64_t (&key)[CAP / 64], int lane)
+{
+    if constexpr (K2 > 2) bitonic_sort<CAP, K2 / 2>(key, lane);
+    bitonic_merge<CAP, K2, K2 / 2>(key, lane);
+}
+
 // Compacts one candidate list.  list[0..cnt) holds keys; entries [0,ver) are known not to be
 // masked.  Drops masked ids, sorts, keeps the best k.  Returns the new count; *tau_out gets the
 // k-th best score (or -inf while fewer than k are held).  Wave-uniform arguments.
+// The user's sorted row of masked ids is first copied into the (still unused) sort buffer when it
+// fits there, so that the binary searches run in LDS after one coalesced read instead of a chain
+// of dependent global loads each.
 template <int CAP>
 __device__ __forceinline__ int wave_compact(uint64_t *__restrict__ list, int cnt, int ver, int k,
                                             const int32_t *__restrict__ mask_idx, int64_t mlo, int64_t mhi,
                                             volatile uint64_t *sortbuf, int lane, float *tau_out)
 {
+    constexpr int EPL = CAP / 64;             // entries per lane
+    constexpr int ROWCAP = CAP * 2;           // int32 ids that fit the sort buffer
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // this wave's own appends are visible
-    int kept = 0;
+    const int64_t L = mhi - mlo;
+    const bool check = mask_idx != nullptr && L > 0 && ver < cnt;
+    const bool staged = check && L <= ROWCAP;
+    volatile int32_t *rowbuf = reinterpret_cast<volatile int32_t *>(sortbuf);
+    if (staged) {
+        for (int j = lane; j < (int)L; j += 64) rowbuf[j] = mask_idx[mlo + j];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    uint64_t keys[EPL];
 #pragma unroll
-    for (int e = lane; e < CAP; e += 64) {
+    for (int q = 0; q < EPL; ++q) {
+        const int e = lane + 64 * q;
         uint64_t key = 0;
         if (e < cnt) {
             key = list[e];
-            if (e >= ver && mask_idx && csr_row_contains(mask_idx, mlo, mhi, key_id(key))) key = 0;
+            if (check && e >= ver) {
+                const int32_t id = key_id(key);
+                bool hit;
+                if (staged) {
+                    int lo = 0, hi = (int)L;
+                    hit = false;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        const int32_t v = rowbuf[mid];
+                        if (v == id) { hit = true; break; }
+                        if (v < id) lo = mid + 1; else hi = mid;
+                    }
+                } else {
+                    hit = csr_row_contains(mask_idx, mlo, mhi, id);
+                }
+                if (hit) key = 0;
+            }
         }
-        sortbuf[e] = key;
-        kept += __popcll(__ballot(key != 0));
+        keys[q] = key;
     }
-    wave_sort_desc<CAP>(sortbuf, lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();          // every lane is done with the staged row
+    int kept = 0;
+#pragma unroll
+    for (int q = 0; q < EPL; ++q) kept += __popcll(__ballot(keys[q] != 0));
+    bitonic_sort<CAP, CAP>(keys, lane);
+#pragma unroll
+    for (int q = 0; q < EPL; ++q) sortbuf[lane + 64 * q] = keys[q];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     const int newc = kept < k ? kept : k;
     for (int e = lane; e < newc; e += 64) list[e] = sortbuf[e];
     *tau_out = newc >= k ? key_score(sortbuf[k - 1]) : -INFINITY;
@@ -164,9 +265,6 @@ __global__ __launch_bounds__(256) void score_topk_kernel(ScoreArgs a)
     char *qbuf = lds;                                                   // [2][TI*ROWB]
     float *bias = reinterpret_cast<float *>(lds + 2 * G::QBYTES);        // [2][TI]
     uint64_t *sortbuf = reinterpret_cast<uint64_t *>(bias + 2 * TI);     // [4][CAP]
-    int *cnt = reinterpret_cast<int *>(sortbuf + 4 * CAP);               // [4][32]
-    int *ver = cnt + 4 * 32;                                             // [4][32]
-    float *tau = reinterpret_cast<float *>(ver + 4 * 32);                // [4][32]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int uj = lane & 31, h = lane >> 5;
@@ -178,7 +276,11 @@ __global__ __launch_bounds__(256) void score_topk_kernel(ScoreArgs a)
     const int64_t it0 = (int64_t)blockIdx.y * a.split_items;             // first item (shard-relative)
     const int64_t it1 = it0 + a.split_items < a.n_items ? it0 + a.split_items : a.n_items;
 
-    if (lane < 32) { cnt[wave * 32 + uj] = 0; ver[wave * 32 + uj] = 0; tau[wave * 32 + uj] = uvalid ? -INFINITY : INFINITY; }
+    // Candidate-list state of the lane's user, kept in registers by BOTH lanes that hold items of
+    // that user (lane and lane^32): entries held, entries already checked against the train row,
+    // and the threshold (the user's k-th best score so far; +inf keeps padding users out).
+    int mycnt = 0, myver = 0;
+    float th = uvalid ? -INFINITY : INFINITY;
 
     // user factors -> B-operand fragments, resident for the whole scan
     const float *prow = a.P + (size_t)(a.p_compact ? urc : (int64_t)user) * a.d;
@@ -266,34 +368,43 @@ __global__ __launch_bounds__(256) void score_topk_kernel(ScoreArgs a)
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? av.w : av.z, pf[2 * c + 1], acc, 0, 0, 0);
                 }
             }
-            // epilogue: filter the lane's 16 items against its user's threshold
-            const float th = tau[wave * 32 + uj];
-            float mx = acc[0];
+            // epilogue: filter the lane's 16 items against its user's threshold.  Passing scores are
+            // rare per lane but not per wave, so every test is first made wave-uniform (a scalar
+            // branch on a ballot): groups of four by their maximum, then the members of a group.
+            float gm[4];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
-            if (mx > th) {
+            for (int g = 0; g < 4; ++g) gm[g] = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3]));
+            const float mx = fmaxf(fmaxf(gm[0], gm[1]), fmaxf(gm[2], gm[3]));
+            if (__ballot(mx > th) != 0) {
                 const int32_t id0 = (int32_t)(a.id_offset + a.item_lo + it0 + step * TI + sb * 32 + 4 * h);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (acc[r] > th) {
-                        const int pos = atomicAdd(&cnt[wave * 32 + uj], 1);
-                        mylist[pos] = make_key(acc[r], id0 + (r & 3) + 8 * (r >> 2));
+                for (int g = 0; g < 4; ++g) {
+                    if (__ballot(gm[g] > th) != 0) {
+#pragma unroll
+                        for (int r = 4 * g; r < 4 * g + 4; ++r) {
+                            const bool pass = acc[r] > th;
+                            if (__ballot(pass) != 0) {
+                                // the user's two lanes append in lane order; both keep the same count
+                                const uint32_t other = swap32(pass ? 1u : 0u, lane);
+                                if (pass) mylist[mycnt + (h ? (int)other : 0)] = make_key(acc[r], id0 + (r & 3) + 8 * (r >> 2));
+                                mycnt += (pass ? 1 : 0) + (int)other;
+                            }
+                        }
                     }
                 }
             }
             // a list that could overflow during the next 32 items is compacted now
-            uint64_t need = __ballot(lane < 32 && cnt[wave * 32 + uj] > CAP - 32);
+            uint64_t need = __ballot(lane < 32 && mycnt > CAP - 32);
             while (need) {
-                const int src = __builtin_ctzll(need);
+                const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(need));
                 need &= need - 1;
                 const int64_t sur = (int64_t)blockIdx.x * 128 + wave * 32 + src;
                 uint64_t *sl = a.lists + ((size_t)blockIdx.y * a.n + sur) * CAP;
                 const int64_t slo = __shfl(mlo, src, 64), shi = __shfl(mhi, src, 64);
                 float nt;
-                const int nc = wave_compact<CAP>(sl, cnt[wave * 32 + src], ver[wave * 32 + src], a.k, a.train_indices, slo, shi,
-                                                 mysort, lane, &nt);
-                if (lane == 0) { cnt[wave * 32 + src] = nc; ver[wave * 32 + src] = nc; tau[wave * 32 + src] = nt; }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const int nc = wave_compact<CAP>(sl, __builtin_amdgcn_readlane(mycnt, src), __builtin_amdgcn_readlane(myver, src), a.k,
+                                                 a.train_indices, slo, shi, mysort, lane, &nt);
+                if (uj == src) { mycnt = nc; myver = nc; th = nt; }
             }
         }
         if (step + 1 < n_steps) store_tile(buf ^ 1);
@@ -307,8 +418,8 @@ __global__ __launch_bounds__(256) void score_topk_kernel(ScoreArgs a)
         uint64_t *sl = a.lists + ((size_t)blockIdx.y * a.n + sur) * CAP;
         const int64_t slo = __shfl(mlo, src, 64), shi = __shfl(mhi, src, 64);
         float nt;
-        const int nc = wave_compact<CAP>(sl, cnt[wave * 32 + src], ver[wave * 32 + src], a.k, a.train_indices, slo, shi, mysort,
-                                         lane, &nt);
+        const int nc = wave_compact<CAP>(sl, __builtin_amdgcn_readlane(mycnt, src), __builtin_amdgcn_readlane(myver, src), a.k,
+                                         a.train_indices, slo, shi, mysort, lane, &nt);
         int32_t *oi = a.out_ids + ((size_t)blockIdx.y * a.n + sur) * a.k;
         float *os = a.out_scores + ((size_t)blockIdx.y * a.n + sur) * a.k;
         for (int e = lane; e < a.k; e += 64) {
