@@ -165,14 +165,13 @@ def main():
 
             if trainer.item_mode == "dense":
                 # replicated item table: the index work of the next batch runs on the auxiliary stream
-                # beside this step's row passes, all-reduce and update
+                # beside this step's all-reduce and update
                 state = {"next": 0}
                 trainer.prepare(0, *batch(0))
 
                 def step(s):
                     k = state["next"]
-                    trainer.prepare((k + 1) & 1, *batch(k + 1))
-                    trainer.step_prepared(k & 1)
+                    trainer.step_prepared(k & 1, prepare_next=((k + 1) & 1,) + tuple(batch(k + 1)))
                     state["next"] = k + 1
             else:
                 def step(s):

@@ -51,3 +51,79 @@ def test_single_rank_sharded_path_matches_unsharded(oracle, item_mode):
     ref = dev.eval_fullrank(tr.P, tr.Q, tr.b, users, (tptr, tidx), (eptr, eidx), k, mean_mode=0)
     np.testing.assert_allclose(m, ref, rtol=1e-6, atol=1e-7)
     dev.close()
+
+
+def _two_rank_worker(rank, world, port, out_dir):
+    """Two ranks share the one GPU of the test box; gloo moves the tensors (RCCL needs a GPU per rank)."""
+    import os
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from tfrec_amd.sharded import ShardedBprTrainer, ShardedEvaluator, make_device
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    dev = make_device(0)
+    cuda = torch.device("cuda", 0)
+    U, I, d, B, k = 4000, 1500, 64, 30000, 20
+    tr = ShardedBprTrainer(dev, U, I, d, 0.01, 0.05, seed=7, item_mode="dense")
+    rng = np.random.default_rng(1)
+    lo, hi = tr.user_range
+    batches = []
+    for _ in range(3):
+        u, i, j = rng.integers(0, U, B).astype(np.int32), rng.integers(0, I, B).astype(np.int32), rng.integers(0, I, B).astype(np.int32)
+        m = (u >= lo) & (u < hi)
+        batches.append([torch.from_numpy(x[m]).to(cuda) for x in (u, i, j)])
+    tr.prepare(0, *batches[0])
+    for s in range(3):
+        nxt = ((s + 1) & 1,) + tuple(batches[s + 1]) if s + 1 < 3 else None
+        tr.step_prepared(s & 1, prepare_next=nxt)
+    P, Q, b = tr.gather_full()
+    deg = 6
+    tptr = torch.arange(0, deg * (U + 1), deg, dtype=torch.int64, device=cuda)
+    tidx = torch.from_numpy(np.sort(rng.integers(0, I, (U, deg)), axis=1).astype(np.int32).ravel()).to(cuda)
+    eptr = torch.arange(0, 2 * (U + 1), 2, dtype=torch.int64, device=cuda)
+    eidx = torch.from_numpy(np.sort(rng.integers(0, I, (U, 2)), axis=1).astype(np.int32).ravel()).to(cuda)
+    users = torch.arange(0, U, 5, dtype=torch.int32, device=cuda)
+    m = ShardedEvaluator(dev, tr, (tptr, tidx), (eptr, eidx), users, top_k=k, chunk_users=300).evaluate()
+    dev.synchronize()
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "two.npz"), P=P.cpu().numpy(), Q=Q.cpu().numpy(), b=b.cpu().numpy(), m=m.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+    dev.close()
+
+
+def test_two_ranks_dense_mode_match_one_rank(tmp_path):
+    """World size 2 with the HIP backend on both ranks: training and evaluation equal the unsharded run."""
+    import socket
+    import torch.multiprocessing as mp
+    from tfrec_amd.device import Device
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = np.load(str(tmp_path / "two.npz"))
+    dev = Device(0)
+    U, I, d, B, k = 4000, 1500, 64, 30000, 20
+    P = dev.uniform((U, d), -0.05, 0.05, 7 * 2 + 1)
+    Q = dev.uniform((I, d), -0.05, 0.05, 7 * 2 + 2)
+    b = dev.zeros(I, np.float32)
+    rng = np.random.default_rng(1)
+    for _ in range(3):
+        u, i, j = rng.integers(0, U, B).astype(np.int32), rng.integers(0, I, B).astype(np.int32), rng.integers(0, I, B).astype(np.int32)
+        dev.bpr_sgd_step(P, Q, b, dev.array(u, np.int32), dev.array(i, np.int32), dev.array(j, np.int32), 0.01, 0.05)
+    dev.synchronize()
+    np.testing.assert_allclose(r["P"], P.numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(r["Q"], Q.numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(r["b"], b.numpy(), rtol=1e-5, atol=1e-7)
+    deg = 6
+    tptr = np.arange(0, deg * (U + 1), deg, dtype=np.int64)
+    tidx = np.sort(rng.integers(0, I, (U, deg)), axis=1).astype(np.int32).ravel()
+    eptr = np.arange(0, 2 * (U + 1), 2, dtype=np.int64)
+    eidx = np.sort(rng.integers(0, I, (U, 2)), axis=1).astype(np.int32).ravel()
+    users = np.arange(0, U, 5, dtype=np.int32)
+    # evaluate the two-rank model unsharded: the item-sharded merge must give the same means
+    P2, Q2, b2 = dev.array(r["P"]), dev.array(r["Q"]), dev.array(r["b"])
+    ref = dev.eval_fullrank(P2, Q2, b2, dev.array(users, np.int32), (dev.array(tptr, np.int64), dev.array(tidx, np.int32)),
+                            (dev.array(eptr, np.int64), dev.array(eidx, np.int32)), k, mean_mode=0)
+    np.testing.assert_allclose(r["m"], ref, rtol=1e-6, atol=1e-7)
+    dev.close()

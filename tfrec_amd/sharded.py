@@ -36,6 +36,14 @@ import torch.distributed as dist
 DENSE_ITEM_BYTES = 256 << 20     # item tables up to this size are replicated rather than sharded
 
 
+def _drain_for_gloo(t, group=None):
+    """gloo moves device tensors through host memory on its own threads; with two ranks on one GPU
+    that has been seen to stall unless the producing stream is drained first.  RCCL orders itself
+    on the stream and needs nothing."""
+    if t.is_cuda and dist.is_initialized() and dist.get_backend(group) == "gloo":
+        torch.cuda.synchronize(t.device)
+
+
 def _part(n, world):
     per = (n + world - 1) // world
     return per
@@ -158,6 +166,7 @@ class ShardedBprTrainer:
         if self.world == 1:
             out.copy_(send)
             return out
+        _drain_for_gloo(send, self.group)
         dist.all_to_all_single(out, send.contiguous(), list(recv_counts), list(send_counts), group=self.group)
         return out
 
@@ -168,15 +177,21 @@ class ShardedBprTrainer:
         self.backend.prepare_batch(slot, self.user_range[1] - self.user_range[0], self.I,
                                    (users.to(torch.int32) - self.user_range[0]).contiguous(), pos.contiguous(), neg.contiguous())
 
-    def step_prepared(self, slot):
-        self._dense_step(None, None, None, slot)
+    def step_prepared(self, slot, prepare_next=None):
+        """Consumes the batch prepared in ``slot``.  ``prepare_next`` = (slot, users, pos, neg) of the
+        batch after it: its index work is enqueued once this step's row passes are, so it runs beside
+        the all-reduce (which leaves the GPU's memory system idle) rather than beside the passes."""
+        self._dense_step(None, None, None, slot, prepare_next)
 
-    def _dense_step(self, users, pos, neg, slot):
+    def _dense_step(self, users, pos, neg, slot, prepare_next=None):
         if users is not None:
             users = (users.to(torch.int32) - self.user_range[0]).contiguous()
             pos, neg = pos.to(torch.int32).contiguous(), neg.to(torch.int32).contiguous()
         self.backend.bpr_dense_grad_step(self.P, self.Q_full, self.b_full, self._G, users, pos, neg, self.lr, self.reg, slot=slot)
+        if prepare_next is not None:
+            self.prepare(*prepare_next)
         if self.world > 1:
+            _drain_for_gloo(self._G, self.group)
             dist.all_reduce(self._G, group=self.group)
         self.backend.axpy(self._Qb, self._G, -self.lr)
 
@@ -236,6 +251,7 @@ class ShardedBprTrainer:
             pad = torch.zeros((per,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
             pad[: x.shape[0]] = x
             outs = [torch.empty_like(pad) for _ in range(self.world)]
+            _drain_for_gloo(pad, self.group)
             dist.all_gather(outs, pad, group=self.group)
             return torch.cat(outs)[:n]
         if self.item_mode == "dense":
@@ -261,6 +277,7 @@ class ShardedEvaluator:
         if t.world == 1:
             return x.unsqueeze(0)
         outs = [torch.empty_like(x) for _ in range(t.world)]
+        _drain_for_gloo(x, t.group)
         dist.all_gather(outs, x.contiguous(), group=t.group)
         return torch.stack(outs)
 
@@ -280,6 +297,7 @@ class ShardedEvaluator:
                 else:
                     rows = torch.empty((n, t.d), dtype=torch.float32, device=dev)
                 if W > 1:
+                    _drain_for_gloo(rows, t.group)
                     dist.broadcast(rows, src=o, group=t.group)
                 ids, sc = self.backend.score_topk_shard(rows, t.Q, t.b, t.item_range[0], eu, k, self.train, self.mode)
                 all_ids, all_sc = self._gather_lists(ids), self._gather_lists(sc)
@@ -289,5 +307,6 @@ class ShardedEvaluator:
                         self.backend.fill_masked(mi, eu, k, self.train)
                     sums += self.backend.metric_sums(mi, eu, k, self.test)
         if W > 1:
+            _drain_for_gloo(sums, t.group)
             dist.all_reduce(sums, group=t.group)
         return (sums / float(self.test_users.shape[0])).to(torch.float32).reshape(5, k)

@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--dist", type=str, default="zipf")
     ap.add_argument("--eval-users", type=int, default=0)
     ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--apr", type=int, default=0, help="time the APR step at this batch size")
+    ap.add_argument("--dns", type=int, default=0, help="time the DNS selection for this many positives (32 candidates each)")
     ap.add_argument("--plain-only", action="store_true", help="only the un-pipelined steps (for counter collection)")
     a = ap.parse_args()
     torch.cuda.set_device(0)
@@ -92,6 +94,44 @@ def main():
         uu = torch.unique(users[:B]).numel(); ui = torch.unique(torch.cat([pos[:B], neg[:B]])).numel()
         print(f"B={B:8d} {a.dist}: {ms:8.3f} ms/step  {rate/1e9:6.3f} G triples/s  algorithmic {alg:5.2f} TB/s ({alg/8*100:4.1f}% of 8 TB/s)"
               f"  uniq users {uu} items {ui}  phases " + " ".join(f"{k}={v*1e3:.0f}us" for k, v in acc.items()), flush=True)
+    if a.apr:
+        B = a.apr
+        users = torch.randint(0, a.U, (B,), device=cuda, generator=gen, dtype=torch.int32)
+        pos = zipf_items(a.I, B, gen, cuda)
+        neg = torch.randint(0, a.I, (B,), device=cuda, generator=gen, dtype=torch.int32)
+        accP, accQ, accb = torch.full_like(P, 0.1), torch.full_like(Q, 0.1), torch.full_like(b, 0.1)
+        dP, dQ, db = torch.zeros_like(P), torch.zeros_like(Q), torch.zeros_like(b)
+        for s_ in range(3):
+            dev.apr_adagrad_step(P, Q, b, accP, accQ, accb, dP, dQ, db, users, pos, neg, 0.05, 0.0, 1.0, 0.5)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for s_ in range(a.steps):
+            dev.apr_adagrad_step(P, Q, b, accP, accQ, accb, dP, dQ, db, users, pos, neg, 0.05, 0.0, 1.0, 0.5)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.steps
+        alg = (84 * a.d + 68) * B / ms * 1e3 / 1e12
+        dev.set_profiling(True)
+        dev.apr_adagrad_step(P, Q, b, accP, accQ, accb, dP, dQ, db, users, pos, neg, 0.05, 0.0, 1.0, 0.5)
+        ph = " ".join(f"{k}={v*1e3:.0f}us" for k, v in dev.phase_times())
+        dev.set_profiling(False)
+        print(f"APR B={B} d={a.d}: {ms:.3f} ms/step  {B/ms*1e3/1e9:.3f} G triples/s  algorithmic {alg:.2f} TB/s ({alg/8*100:.1f}% of 8 TB/s)  {ph}", flush=True)
+    if a.dns:
+        n, Cn = a.dns, 32
+        users = torch.randint(0, a.U, (n,), device=cuda, generator=gen, dtype=torch.int32)
+        cand = torch.randint(0, a.I, (n, Cn), device=cuda, generator=gen, dtype=torch.int32)
+        out = torch.empty(n, device=cuda, dtype=torch.int32)
+        for s_ in range(3):
+            dev.dns_select(P, Q, b, users, cand, out=out)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for s_ in range(a.steps):
+            dev.dns_select(P, Q, b, users, cand, out=out)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.steps
+        alg = ((Cn + 1) * 4 * a.d + 8 * Cn) * n / ms * 1e3 / 1e12
+        print(f"DNS select n={n} C={Cn} d={a.d}: {ms:.3f} ms  {n/ms*1e3/1e9:.3f} G positives/s  algorithmic {alg:.2f} TB/s ({alg/8*100:.1f}% of 8 TB/s)", flush=True)
     if a.eval_users:
         n = a.eval_users
         eu = torch.arange(n, device=cuda, dtype=torch.int32)
