@@ -10,7 +10,7 @@ d=64, fp32); N>1 (launched by torch.distributed.run, one rank per GPU) runs the 
 tables with an all-to-all exchange of item rows and gradients per step, weak scaling (the
 per-GPU batch is fixed).  Rank 0 prints ONE JSON line.
 
-Extra objects on that line: "roofline" (the step's kernels against the HBM roofline, timed
+Extra objects on that line: "other_paths" (APR step and DNS selection on the same tables), "roofline" (the step's kernels against the HBM roofline, timed
 with HIP events on the stream the library launches on), "cpu_baseline" (the CPU oracle timed
 on this host, rank 0, N=1 only) and "eval" (full-rank evaluation users/s, timed separately,
 outside the K training steps).
@@ -43,6 +43,63 @@ def zipf_items(n_items, size, gen, device, alpha=1.0):
         n = min(chunk, size - s)
         r = torch.rand(n, device=device, dtype=torch.float64, generator=gen)
         out[s:s + n] = perm[torch.searchsorted(cdf, r).clamp_(max=n_items - 1)].to(torch.int32)
+    return out
+
+
+def pmc_traffic(B, d):
+    """HBM bytes per step from the committed counter passes (profiles/pmc_traffic.json, written by
+    tools/make_profile_summary.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same
+    workload); None when the file does not describe this batch size and factor size."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except (OSError, ValueError):
+        return None
+    if t.get("workload_batch") != B or t.get("factors") != d:
+        return None
+    return t["bytes_per_step"]
+
+
+def other_paths(dev, P, Q, b, U, I, d, B, gen, cuda, steps=10):
+    """APR step (model/APR.py:156-164) and DNS selection (model/DNSBPR.py:68-79) on the same tables:
+    throughput and the algorithmic HBM rate; timed outside the K steps of the headline metric."""
+    out = {}
+    users = torch.randint(0, U, (B,), device=cuda, generator=gen, dtype=torch.int32)
+    pos = zipf_items(I, B, gen, cuda)
+    neg = torch.randint(0, I, (B,), device=cuda, generator=gen, dtype=torch.int32)
+    Pa, Qa, ba = P.clone(), Q.clone(), b.clone()
+    acc = [torch.full_like(x, 0.1) for x in (Pa, Qa, ba)]
+    dl = [torch.zeros_like(x) for x in (Pa, Qa, ba)]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def apr():
+        dev.apr_adagrad_step(Pa, Qa, ba, acc[0], acc[1], acc[2], dl[0], dl[1], dl[2], users, pos, neg, 0.05, 0.0, 1.0, 0.5)
+    for _ in range(3):
+        apr()
+    e0.record()
+    for _ in range(steps):
+        apr()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    gbs = (84 * d + 68) * B / (ms * 1e-3) / 1e9
+    out["apr_adagrad_step"] = {"triples_per_s": B / (ms * 1e-3), "ms_per_step": ms, "batch": B,
+                               "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                            "algorithmic_bytes_per_triple": 84 * d + 68}}
+    del acc, dl, Pa, Qa, ba
+    Cn = 32
+    cand = torch.randint(0, I, (B, Cn), device=cuda, generator=gen, dtype=torch.int32)
+    sel = torch.empty(B, device=cuda, dtype=torch.int32)
+    for _ in range(3):
+        dev.dns_select(P, Q, b, users, cand, out=sel)
+    e0.record()
+    for _ in range(steps):
+        dev.dns_select(P, Q, b, users, cand, out=sel)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    per = (Cn + 1) * 4 * d + 8 * Cn
+    gbs = per * B / (ms * 1e-3) / 1e9
+    out["dns_select"] = {"positives_per_s": B / (ms * 1e-3), "ms": ms, "positives": B, "candidates": Cn,
+                         "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                      "algorithmic_bytes_per_positive": per}}
     return out
 
 
@@ -87,6 +144,7 @@ def main():
     ap.add_argument("--topk", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
+    ap.add_argument("--no-other", action="store_true", help="skip the APR step and DNS selection timings")
     ap.add_argument("--prep-batches", type=int, default=1, help="batches sorted per index preparation (single GPU)")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU code path even on one GPU (testing)")
     ap.add_argument("--item-mode", default="auto", choices=["auto", "dense", "sharded"],
@@ -237,7 +295,7 @@ def main():
             achieved = B * alg_bytes_per_triple / (dev_ms / args.steps * 1e-3) / 1e9
             out["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(B, d),
                 "kernel": "one BPR step = build_keys + radix sort + seg_tile/seg_fixup (user side) + seg_tile/seg_fixup (item side)",
                 "algorithmic_bytes_per_triple": alg_bytes_per_triple,
                 "device_ms_per_step": dev_ms / args.steps,
@@ -283,6 +341,8 @@ def main():
                                 "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS[name], "unit": "TFLOP/s",
                                              "frac": tf / MFMA_PEAK_TFLOPS[name]}}
                 out["eval"] = ev
+            if not args.no_other:
+                out["other_paths"] = other_paths(dev, P, Q, b, U, I, d, B, gen, cuda)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(U, I, d, 1 << 17, lr, reg)
         if rank == 0:

@@ -1,6 +1,12 @@
-"""Builds profiles/<tag>_summary.md from rocprofv3 outputs merged into gpurun_out/ (developer tool).
+"""Builds profiles/<tag>_summary.md and profiles/pmc_traffic.json from rocprofv3 outputs merged into
+gpurun_out/ (developer tool).
 
-  python tools/make_profile_summary.py r1 gpurun_out/prof_r1b gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/bench2.json
+  python tools/make_profile_summary.py r1 gpurun_out/prof_stats gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/bench.json
+
+  prof_stats: rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline
+  pmc_fetch / pmc_write: rocprofv3 --pmc FETCH_SIZE (WRITE_SIZE) --output-format csv -- python3 bench.py --steps 5 --warmup 2
+                         --no-eval --no-cpu-baseline --no-other   (one pass each)
+  bench.json: the JSON line of an un-profiled default run
 """
 import collections
 import csv
@@ -9,58 +15,91 @@ import os
 import shutil
 import sys
 
+STEP_KERNELS = ("seg_tile_kernel", "seg_fixup_kernel", "build_keys_kernel", "sort_hist_kernel", "sort_scan_kernel", "sort_scatter_kernel",
+                "loss_finalize")
+# FETCH_SIZE (KiB) counts memory-side read requests at 64 bytes each.  Streaming reads issue one 128-byte
+# request per line (bytes = 2 x FETCH_SIZE x 1024, the microarchitecture guide's correction); gathers of
+# 256-byte rows were calibrated with tools/pmc_calibrate.py at 1.5 requests per 128 bytes
+# (bytes = 1.333 x FETCH_SIZE x 1024).  WRITE_SIZE (KiB) is exact.
+GATHER_KERNELS = ("seg_tile_kernel", "seg_fixup_kernel")
+
+
+def find(d, suffix):
+    for r, _, fs in os.walk(d):
+        for f in fs:
+            if f.endswith(suffix):
+                return os.path.join(r, f)
+    raise SystemExit("no *%s under %s" % (suffix, d))
+
+
+def short(name):
+    for k in STEP_KERNELS:
+        if k in name:
+            pol = ""
+            for p in ("BprUserPol", "BprItemPol", "RowsApplyPol"):
+                if p in name:
+                    pol = "<" + p + ">"
+            return k + pol
+    return None
+
 
 def main():
     tag, stats_dir, fetch_dir, write_dir, bench_json = sys.argv[1:6]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     prof = os.path.join(root, "profiles")
     os.makedirs(prof, exist_ok=True)
-    stats = [f for f in os.listdir(stats_dir) if f.endswith("kernel_stats.csv")][0]
-    shutil.copy(os.path.join(stats_dir, stats), os.path.join(prof, tag + "_bench_kernel_stats.csv"))
-    shutil.copy(bench_json, os.path.join(prof, tag + "_bench_line.json"))
+    stats = find(stats_dir, "kernel_stats.csv")
+    shutil.copy(stats, os.path.join(prof, tag + "_bench_kernel_stats.csv"))
     line = json.loads(open(bench_json).read().strip().splitlines()[-1])
-    rows = list(csv.DictReader(open(os.path.join(stats_dir, stats))))
+    json.dump(line, open(os.path.join(prof, tag + "_bench_line.json"), "w"), indent=1)
+    rows = list(csv.DictReader(open(stats)))
+    rf = line["roofline"]
     out = ["# %s profile (MI355X, 1 GPU)" % tag, "",
            "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline`;",
            "raw table: `profiles/%s_bench_kernel_stats.csv`; bench line of the un-profiled run: `profiles/%s_bench_line.json`." % (tag, tag), "",
-           "Un-profiled bench: **%.3f G triples/s**, %.3f ms/step, roofline.frac %.3f; phases (HIP events, ms): %s" % (
-               line["value"] / 1e9, line["ms_per_step"], line["roofline"]["frac"],
-               ", ".join("%s %.3f" % kv for kv in line["roofline"]["phases_ms"].items())), "",
+           "Un-profiled bench: **%.3f G triples/s**, %.3f ms/step, roofline.frac %.3f; phases of an un-pipelined step (HIP events, ms): %s" % (
+               line["value"] / 1e9, line["ms_per_step"], rf["frac"], ", ".join("%s %.3f" % kv for kv in rf["phases_ms"].items())), "",
            "| kernel | calls | avg us | % of GPU time |", "|---|---|---|---|"]
-    for r in rows[:16]:
-        out.append("| `%s` | %s | %.1f | %s |" % (r["Name"][:100].replace("|", "/"), r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    for r in rows[:18]:
+        out.append("| `%s` | %s | %.1f | %s |" % (r["Name"][:110].replace("|", "/"), r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
     out.append("")
 
-    def agg(d, counter):
+    def per_kernel(d, counter):
         a = collections.defaultdict(list)
-        f = [x for x in os.listdir(d) if x.endswith("counter_collection.csv")][0]
-        for r in csv.DictReader(open(os.path.join(d, f))):
+        for r in csv.DictReader(open(find(d, "counter_collection.csv"))):
             if r["Counter_Name"] == counter:
-                a[r["Kernel_Name"][:70]].append(float(r["Counter_Value"]))
+                k = short(r["Kernel_Name"])
+                if k:
+                    a[k].append(float(r["Counter_Value"]))
         return a
-    if os.path.isdir(fetch_dir) and os.path.isdir(write_dir):
-        f, w = agg(fetch_dir, "FETCH_SIZE"), agg(write_dir, "WRITE_SIZE")
-        out += ["## HBM traffic per launch", "",
-                "Separate passes `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` over `python3 bench.py --steps 5 --warmup 2 --no-eval --no-cpu-baseline`.",
-                "Both counters are in KiB.  On gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so fetched bytes = 2 x FETCH_SIZE x 1024;",
-                "WRITE_SIZE is exact.  Values below are the median over the full-size launches.", "",
-                "| kernel | fetched MB | written MB | total MB |", "|---|---|---|---|"]
-        tot = 0.0
-        for k in f:
-            if "seg_" in k or "build_keys" in k or "rocprim" in k:
-                big = [x for x in f[k] if x > max(f[k]) / 4] or [0]
-                wl = w.get(k, [0]); wbig = [x for x in wl if x > max(wl) / 4] or [0]
-                fm = 2 * sorted(big)[len(big) // 2] * 1024 / 1e6
-                wm = sorted(wbig)[len(wbig) // 2] * 1024 / 1e6
-                n = 1
-                if "rocprim" in k:
-                    continue
-                tot += fm + wm
-                out.append("| `%s` | %.0f | %.0f | %.0f |" % (k.replace("|", "/"), fm, wm, fm + wm))
-        B = line["config"]["batch_per_gpu"]
-        alg = B * line["roofline"]["algorithmic_bytes_per_triple"] / 1e6
-        out += ["", "Algorithmic bytes per step: %d x %d = %.0f MB; measured traffic of the row and key kernels: %.0f MB (%.2fx)." % (
-            B, line["roofline"]["algorithmic_bytes_per_triple"], alg, tot, tot / alg), ""]
+    f, w = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+    steps = max(len(f.get("seg_tile_kernel<BprUserPol>", [])), 1)
+    out += ["## HBM traffic per step (PMC)", "",
+            "Separate passes `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` over `python3 bench.py --steps 5 --warmup 2 --no-eval",
+            "--no-cpu-baseline --no-other` (%d steps in the pass).  Both counters are KiB.  FETCH_SIZE tallies memory-side read requests at" % steps,
+            "64 bytes: streaming kernels issue one request per 128-byte line (bytes = 2 x FETCH_SIZE x 1024, the guide's gfx950 correction);",
+            "gathers of 256-byte rows issue 1.5 requests per 128 bytes (calibrated with `tools/pmc_calibrate.py`: 2^21 random 256-byte rows",
+            "= 537 MB read, FETCH_SIZE 393,119 KiB), so the row kernels use bytes = 1.333 x FETCH_SIZE x 1024.  WRITE_SIZE is exact.",
+            "Per-step figure = sum over all launches in the pass / steps.", "",
+            "| kernel | launches/step | fetched MB/step (guide x2) | fetched MB/step (calibrated) | written MB/step |", "|---|---|---|---|---|"]
+    tot_guide = tot_cal = tot_w = 0.0
+    for k in sorted(set(f) | set(w)):
+        fk = sum(f.get(k, [0])) * 1024 / 1e6 / steps
+        wk = sum(w.get(k, [0])) * 1024 / 1e6 / steps
+        cal = fk * (1.3333 if k.startswith(GATHER_KERNELS) else 2.0)
+        tot_guide += 2 * fk; tot_cal += cal; tot_w += wk
+        out.append("| `%s` | %.1f | %.0f | %.0f | %.0f |" % (k, len(f.get(k, [])) / steps, 2 * fk, cal, wk))
+    B = line["config"]["batch_per_gpu"]
+    alg = B * rf["algorithmic_bytes_per_triple"] / 1e6
+    out += ["", "Per step: fetched %.0f MB (guide x2) / %.0f MB (calibrated), written %.0f MB; total %.0f MB (calibrated)." % (
+                tot_guide, tot_cal, tot_w, tot_cal + tot_w),
+            "Algorithmic bytes per step: %d x %d = %.0f MB, so measured traffic is %.2fx algorithmic (calibrated; %.2fx with the guide's x2)." % (
+                B, rf["algorithmic_bytes_per_triple"], alg, (tot_cal + tot_w) / alg, (tot_guide + tot_w) / alg), ""]
+    json.dump({"workload_batch": B, "factors": line["config"]["factors"],
+               "bytes_per_step": (tot_cal + tot_w) * 1e6, "bytes_per_step_guide_x2": (tot_guide + tot_w) * 1e6,
+               "fetched_bytes_per_step": tot_cal * 1e6, "written_bytes_per_step": tot_w * 1e6,
+               "source": "profiles/%s_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % tag},
+              open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
     open(os.path.join(prof, tag + "_summary.md"), "w").write("\n".join(out) + "\n")
     print("\n".join(out))
 
