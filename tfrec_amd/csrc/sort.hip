@@ -16,9 +16,7 @@
 #ifndef TF_SORT_RB_MAX
 #define TF_SORT_RB_MAX 8
 #endif
-#ifndef TF_SORT_ITEMS
-#define TF_SORT_ITEMS 8
-#endif
+
 
 namespace {
 
@@ -197,12 +195,14 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t *__res
     }
 }
 
-constexpr int SORT_ITEMS = TF_SORT_ITEMS;        // pairs per lane: tiles of 256 * SORT_ITEMS pairs
-constexpr int SORT_TILE = 256 * SORT_ITEMS;
 constexpr int SORT_RB_MAX = TF_SORT_RB_MAX;      // widest digit
 
+// Pairs per lane: tiles of 4096 pairs move data best; below about a million pairs there are too few
+// such tiles to occupy the device, and tiles of 2048 finish sooner.
+inline int sort_items_for(size_t n) { return n >= ((size_t)1 << 20) ? 16 : 8; }
+
 struct SortPlan {
-    int passes, rb;
+    int passes, rb, items;
     uint32_t nblk;
     size_t counts_bytes, total_bytes, tmp_bytes;
 };
@@ -214,23 +214,35 @@ SortPlan sort_plan(size_t n, int end_bit)
     p.passes = (end_bit + SORT_RB_MAX - 1) / SORT_RB_MAX;
     p.rb = (end_bit + p.passes - 1) / p.passes;
     if (p.rb < 6) p.rb = 6;
-    p.nblk = (uint32_t)((n + SORT_TILE - 1) / SORT_TILE);
+    p.items = sort_items_for(n);
+    const size_t tile = (size_t)256 * p.items;
+    p.nblk = (uint32_t)((n + tile - 1) / tile);
     if (p.nblk == 0) p.nblk = 1;
-    p.counts_bytes = tf_align(sizeof(uint32_t) * ((size_t)1 << p.rb) * p.nblk);
+    // sized for the smaller tile, so that the byte count does not depend on the tile choice
+    const size_t nblk_max = (n + 2047) / 2048 + 1;
+    p.counts_bytes = tf_align(sizeof(uint32_t) * ((size_t)1 << p.rb) * nblk_max);
     p.total_bytes = tf_align(sizeof(uint32_t) * ((size_t)1 << p.rb));
     p.tmp_bytes = p.passes > 1 ? tf_align(sizeof(uint32_t) * n) : 0;
     return p;
 }
 
-template <int RB>
+template <int RB, int ITEMS>
 int sort_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, uint32_t n, int shift, uint32_t dmask,
               uint32_t *counts, uint32_t *totals, uint32_t nblk, hipStream_t stream)
 {
-    sort_hist_kernel<RB, SORT_ITEMS><<<nblk, 256, 0, stream>>>(kin, n, shift, dmask, counts, nblk);
+    sort_hist_kernel<RB, ITEMS><<<nblk, 256, 0, stream>>>(kin, n, shift, dmask, counts, nblk);
     sort_scan_kernel<<<1 << RB, 256, 0, stream>>>(counts, nblk, totals);
-    sort_scatter_kernel<RB, SORT_ITEMS><<<nblk, 256, 0, stream>>>(kin, vin, kout, vout, n, shift, dmask, counts, totals, nblk);
+    sort_scatter_kernel<RB, ITEMS><<<nblk, 256, 0, stream>>>(kin, vin, kout, vout, n, shift, dmask, counts, totals, nblk);
     TF_HIP(hipGetLastError());
     return TFREC_OK;
+}
+
+template <int RB>
+int sort_pass_items(int items, const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, uint32_t n, int shift,
+                    uint32_t dmask, uint32_t *counts, uint32_t *totals, uint32_t nblk, hipStream_t stream)
+{
+    if (items == 16) return sort_pass<RB, 16>(kin, vin, kout, vout, n, shift, dmask, counts, totals, nblk, stream);
+    return sort_pass<RB, 8>(kin, vin, kout, vout, n, shift, dmask, counts, totals, nblk, stream);
 }
 
 }  // namespace
@@ -264,12 +276,12 @@ int tfrec_sort_pairs(void *d_temp, size_t temp_bytes, const uint32_t *keys_in, u
         const uint32_t dmask = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
         int rc = TFREC_EUNSUP;
         switch (p.rb) {
-            case 6: rc = sort_pass<6>(kin, vin, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream); break;
-            case 7: rc = sort_pass<7>(kin, vin, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream); break;
-            case 8: rc = sort_pass<8>(kin, vin, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream); break;
-            case 9: rc = sort_pass<9>(kin, vin, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream); break;
-            case 10: rc = sort_pass<10>(kin, vin, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream); break;
-            case 11: rc = sort_pass<11>(kin, vin, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream); break;
+            case 6: rc = sort_pass_items<6>(p.items, kin, vin, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream); break;
+            case 7: rc = sort_pass_items<7>(p.items, kin, vin, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream); break;
+            case 8: rc = sort_pass_items<8>(p.items, kin, vin, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream); break;
+            case 9: rc = sort_pass_items<9>(p.items, kin, vin, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream); break;
+            case 10: rc = sort_pass_items<10>(p.items, kin, vin, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream); break;
+            case 11: rc = sort_pass_items<11>(p.items, kin, vin, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream); break;
             default: tfrec_set_error("internal: no sort kernel for %d-bit digits", p.rb);
         }
         if (rc != TFREC_OK) return rc;
