@@ -248,7 +248,7 @@ struct ScoreArgs {
 template <int D, bool BF16, int CAP>
 struct ScoreGeom {
     static constexpr int ESZ = BF16 ? 2 : 4;
-    static constexpr int TI = (D * ESZ >= 512) ? 64 : 128;   // items per step
+    static constexpr int TI = (D * ESZ >= (BF16 ? 512 : 256)) ? 64 : 128;   // items per step
     static constexpr int ROWB = D * ESZ + 16;                // padded LDS row (bank spread)
     static constexpr int CPR = D * ESZ / 16;                 // 16-byte chunks per row
     static constexpr int NLD = TI * CPR / 256;               // chunks per thread per tile
@@ -675,7 +675,7 @@ static int plan_score(const float *d_Q, int d, int64_t item_lo, int64_t item_hi,
     p->n_items = item_hi - item_lo;
     p->bf16 = score_mode == TFREC_SCORE_BF16;
     p->direct = !p->bf16 && d == p->D && (((uintptr_t)d_Q) & 15u) == 0;
-    p->TI = (p->D * (p->bf16 ? 2 : 4) >= 512) ? 64 : 128;
+    p->TI = (p->D * (p->bf16 ? 2 : 4) >= (p->bf16 ? 512 : 256)) ? 64 : 128;
     p->chunk = 1 << 20;          // users per launch: bounds the candidate-list workspace
     const int64_t user_blocks_all = (n + 127) / 128;
     int splits = 1;
