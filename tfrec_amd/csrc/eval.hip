@@ -157,20 +157,24 @@ __device__ __forceinline__ int wave_compact(uint64_t *__restrict__ list, int cnt
     const bool check = mask_idx != nullptr && L > 0 && ver < cnt;
     const bool staged = check && L <= ROWCAP;
     volatile int32_t *rowbuf = reinterpret_cast<volatile int32_t *>(sortbuf);
+    // the list entries and the masked row are requested together (one memory round trip, not two)
+    uint64_t keys[EPL];
+#pragma unroll
+    for (int q = 0; q < EPL; ++q) {
+        const int e = lane + 64 * q;
+        keys[q] = e < cnt ? list[e] : 0;
+    }
     if (staged) {
         for (int j = lane; j < (int)L; j += 64) rowbuf[j] = mask_idx[mlo + j];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    uint64_t keys[EPL];
+    if (check) {
 #pragma unroll
-    for (int q = 0; q < EPL; ++q) {
-        const int e = lane + 64 * q;
-        uint64_t key = 0;
-        if (e < cnt) {
-            key = list[e];
-            if (check && e >= ver) {
-                const int32_t id = key_id(key);
+        for (int q = 0; q < EPL; ++q) {
+            const int e = lane + 64 * q;
+            if (e < cnt && e >= ver) {
+                const int32_t id = key_id(keys[q]);
                 bool hit;
                 if (staged) {
                     int lo = 0, hi = (int)L;
@@ -184,10 +188,9 @@ __device__ __forceinline__ int wave_compact(uint64_t *__restrict__ list, int cnt
                 } else {
                     hit = csr_row_contains(mask_idx, mlo, mhi, id);
                 }
-                if (hit) key = 0;
+                if (hit) keys[q] = 0;
             }
         }
-        keys[q] = key;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();          // every lane is done with the staged row
