@@ -249,3 +249,38 @@ def test_sort_pairs_is_a_stable_sort(dev, n, bits):
     order = np.argsort(keys, kind="stable")
     assert np.array_equal(ko.numpy(), keys[order])
     assert np.array_equal(vo.numpy(), vals[order])
+
+
+def test_axpy_and_dense_grad_step_contract(dev):
+    """tfrec_axpy is an exact fused multiply-add; the dense gradient step rejects bad arguments and,
+    followed by axpy, equals the plain step bit for bit (same arithmetic in the same order)."""
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 1024, 4099):
+        y, x = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+        dy = dev.array(y)
+        dev.axpy(dy, dev.array(x), -0.37)
+        dev.synchronize()
+        want = np.array([np.float32(np.float64(np.float32(-0.37)) * np.float64(a) + np.float64(b)) for a, b in zip(x, y)], np.float32)
+        assert np.array_equal(dy.numpy(), want)
+    U, I, d, B = 300, 200, 64, 5000
+    P = rng.uniform(-0.3, 0.3, (U, d)).astype(np.float32)
+    Q = rng.uniform(-0.3, 0.3, (I, d)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, I).astype(np.float32)
+    u, i, j = [rng.integers(0, n, B).astype(np.int32) for n in (U, I, I)]
+    P1, Q1, b1, _ = run_bpr(dev, P, Q, b, u, i, j, 0.01, 0.05, want_loss=False)
+    dP = dev.array(P)
+    G = dev.array(np.full(I * d + I, 7.0, np.float32))       # stale contents must not leak into the sums
+    dQ, db = dev.array(Q), dev.array(b)
+    dev.bpr_dense_grad_step(dP, dQ, db, G, dev.array(u), dev.array(i), dev.array(j), 0.01, 0.05)
+    g = G.numpy()
+    untouched = np.setdiff1d(np.arange(I), np.concatenate([i, j]))
+    assert not g[:I * d].reshape(I, d)[untouched].any() and not g[I * d:][untouched].any()
+    assert np.array_equal(dQ.numpy(), Q) and np.array_equal(db.numpy(), b)      # the item tables are read-only here
+    dev.axpy(dQ, G.view(0, I * d), -0.01, n=I * d)
+    dev.axpy(db, G.view(I * d, I * d + I), -0.01, n=I)
+    dev.synchronize()
+    assert np.array_equal(dP.numpy(), P1) and np.array_equal(dQ.numpy(), Q1) and np.array_equal(db.numpy(), b1)
+    with pytest.raises(ValueError):
+        dev.bpr_dense_grad_step(dP, dQ, db, G, dev.array(u), dev.array(i), dev.array(j), 0.01, 0.05, slot=5)
+    with pytest.raises(ValueError):
+        dev.bpr_dense_grad_step(dP, dQ, db, G, None, None, None, 0.01, 0.05, slot=0)     # nothing prepared in slot 0
