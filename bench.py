@@ -149,6 +149,8 @@ def main():
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU code path even on one GPU (testing)")
     ap.add_argument("--item-mode", default="auto", choices=["auto", "dense", "sharded"],
                     help="multi-GPU item table: replicated with one all-reduce of gradient sums per step, or sharded with all-to-all lookups")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend for N>1 (gloo: testing only)")
+    ap.add_argument("--single-device", action="store_true", help="testing: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--extras", action="store_true", help="also time the reference batch size (512 triples per step)")
     args = ap.parse_args()
 
@@ -159,11 +161,16 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     cuda = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=cuda)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=cuda)
+        else:
+            dist.init_process_group("gloo")
 
     from tfrec_amd.device import Device, SCORE_F32, SCORE_BF16
     stream = torch.cuda.Stream(device=cuda)
