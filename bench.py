@@ -100,6 +100,30 @@ def other_paths(dev, P, Q, b, U, I, d, B, gen, cuda, steps=10):
     out["dns_select"] = {"positives_per_s": B / (ms * 1e-3), "ms": ms, "positives": B, "candidates": Cn,
                          "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                       "algorithmic_bytes_per_positive": per}}
+    del cand, sel
+    # device epoch pipeline: draw one negative per stored interaction (rejection against the user's row),
+    # shuffle, gather -- the work of model/BPR.py:50-62 + data/dataiterator.py:52-54 for one epoch
+    deg = 16
+    nnz = U * deg
+    indptr = torch.arange(0, nnz + 1, deg, device=cuda, dtype=torch.int64)
+    indices = torch.sort(torch.randint(0, I, (U, deg), device=cuda, generator=gen, dtype=torch.int32), dim=1).values.reshape(-1).contiguous()
+    eu, ep, en = (torch.empty(nnz, device=cuda, dtype=torch.int32) for _ in range(3))
+    su, sp, sn = (torch.empty(nnz, device=cuda, dtype=torch.int32) for _ in range(3))
+    perm = torch.empty(nnz, device=cuda, dtype=torch.int32)
+
+    def epoch(e):
+        dev.sample_negatives(indptr, indices, U, I, 1, 2018, 2 * e, users_out=eu, pos_out=ep, neg_out=en)
+        dev.shuffle_perm(nnz, 2018, 2 * e + 1, out=perm)
+        dev.gather_rows_i32(eu, perm, out=su); dev.gather_rows_i32(ep, perm, out=sp); dev.gather_rows_i32(en, perm, out=sn)
+    epoch(0)
+    torch.cuda.synchronize()
+    e0.record()
+    for e in range(1, 4):
+        epoch(e)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    out["device_epoch_pipeline"] = {"triples_per_s": nnz / (ms * 1e-3), "ms_per_epoch": ms, "interactions": nnz,
+                                    "note": "sample + shuffle + gather of one epoch; the host sampler of the reference is O(items) per user on one core"}
     return out
 
 

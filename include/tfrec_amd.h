@@ -101,6 +101,25 @@ int tfrec_mf_predict(tfrec_ctx *ctx, const float *d_P, const float *d_Q, const f
 int tfrec_sort_pairs_u32(tfrec_ctx *ctx, const uint32_t *d_keys_in, const uint32_t *d_vals_in,
                          uint32_t *d_keys_out, uint32_t *d_vals_out, int64_t n, int key_bits);
 
+/* ---- epoch pipeline on the device ------------------------------------------------------------ */
+/* One training epoch's triples without the host: replaces BPR.get_training_data (model/BPR.py:50-62),
+ * i.e. utils/tools.py:39-49 random_choice(all_items, size=len(pos), exclusion=pos) per user, and the
+ * shuffle of data/dataiterator.py:52-54.  For every stored interaction t (CSR order, rows sorted
+ * ascending) writes its user, its item and n_neg items drawn uniformly, with replacement, from the
+ * items NOT in the user's row (rejection against the row).  The random numbers are a counter-based
+ * hash of (seed, stream, t * n_neg + c, attempt) -- not numpy's stream, which cannot be drawn in
+ * parallel -- so the output is a pure function of the arguments.  d_users_out / d_pos_out may be
+ * null.  A user who holds every item raises the bad-index flag (TFREC_EINDEX at synchronize). */
+int tfrec_sample_negatives(tfrec_ctx *ctx, const int64_t *d_indptr, const int32_t *d_indices,
+                           int64_t U, int64_t I, int64_t nnz, int n_neg, uint64_t seed, uint64_t stream,
+                           int32_t *d_users_out, int32_t *d_pos_out, int32_t *d_neg_out);
+/* A permutation of 0..n-1 that is a pure function of (seed, stream, n): stable sort of 32-bit hash
+ * keys (the shuffle of data/dataiterator.py:52-54). */
+int tfrec_shuffle_perm(tfrec_ctx *ctx, int64_t n, uint64_t seed, uint64_t stream, int32_t *d_perm_out);
+/* dst[r, :] = src[perm[r], :] for rows of `width` int32 (applies a shuffle to index arrays). */
+int tfrec_gather_rows_i32(tfrec_ctx *ctx, const int32_t *d_src, int64_t n_src, const int32_t *d_perm,
+                          int64_t n, int width, int32_t *d_dst);
+
 /* ---- training steps ------------------------------------------------------------------------ */
 /* One BPR-MF minibatch step with plain SGD: the graph of model/BPR.py:36-48 (identical in
  * model/DNSBPR.py:35-47) executed by sess.run(self.update) at model/BPR.py:72.

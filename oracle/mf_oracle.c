@@ -436,3 +436,67 @@ int oracle_eval_fullrank(const float *P, const float *Q, const float *b, int64_t
     free(score); free(rank); free(cur); free(sum);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Device epoch pipeline (no numpy stream can be drawn in parallel, so the GPU sampler defines its own
+ * counter-based draws; this is the same arithmetic on the CPU, the checker of
+ * tfrec_sample_negatives / tfrec_shuffle_perm).  Distribution and exclusion rule follow
+ * model/BPR.py:50-62 and utils/tools.py:39-49: per stored interaction, n_neg uniform draws with
+ * replacement from the items NOT in the user's row.
+ * ------------------------------------------------------------------------------------------ */
+static uint64_t o_mix64(uint64_t x)
+{
+    x += 0x9e3779b97f4a7c15ull;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+static uint64_t o_draw64(uint64_t seed, uint64_t stream, uint64_t index, uint32_t attempt)
+{
+    return o_mix64(o_mix64(seed ^ (stream * 0xd1342543de82ef95ull)) + index * 0x2545f4914f6cdd1dull + (uint64_t)attempt * 0x9e3779b97f4a7c15ull);
+}
+static int o_row_contains(const int32_t *idx, int64_t lo, int64_t hi, int32_t id)
+{
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (idx[mid] == id) return 1;
+        if (idx[mid] < id) lo = mid + 1; else hi = mid;
+    }
+    return 0;
+}
+/* returns the number of users whose row holds every item (nothing to draw; their negatives are 0) */
+int64_t oracle_sample_negatives(const int64_t *indptr, const int32_t *indices, int64_t U, int64_t I, int n_neg, uint64_t seed,
+                                uint64_t stream, int32_t *users_out, int32_t *pos_out, int32_t *neg_out)
+{
+    int64_t n_full = 0;
+    for (int64_t u = 0; u < U; ++u) {
+        const int64_t r0 = indptr[u], r1 = indptr[u + 1];
+        const int full = (r1 - r0) >= I;
+        if (full && r1 > r0) ++n_full;
+        for (int64_t t = r0; t < r1; ++t) {
+            users_out[t] = (int32_t)u;
+            pos_out[t] = indices[t];
+            for (int c = 0; c < n_neg; ++c) {
+                const uint64_t index = (uint64_t)t * (uint64_t)n_neg + (uint64_t)c;
+                uint32_t cand = 0;
+                if (!full) {
+                    int ok = 0;
+                    for (uint32_t a = 0; a < 64u && !ok; ++a) {
+                        cand = (uint32_t)(((unsigned __int128)o_draw64(seed, stream, index, a) * (unsigned __int128)(uint64_t)I) >> 64);
+                        ok = !o_row_contains(indices, r0, r1, (int32_t)cand);
+                    }
+                    while (!ok) {
+                        cand = cand + 1 == (uint32_t)I ? 0u : cand + 1;
+                        ok = !o_row_contains(indices, r0, r1, (int32_t)cand);
+                    }
+                }
+                neg_out[index] = (int32_t)cand;
+            }
+        }
+    }
+    return n_full;
+}
+void oracle_shuffle_keys(int64_t n, uint64_t seed, uint64_t stream, uint32_t *keys_out)
+{
+    for (int64_t t = 0; t < n; ++t) keys_out[t] = (uint32_t)(o_draw64(seed, stream ^ 0x73687566666c65ull, (uint64_t)t, 0) >> 32);
+}

@@ -185,6 +185,28 @@ def eval_dense(R, train_dict, test_dict, k):
 # --------------------------------------------------------------------------- #
 # host-side sampling / batching restatements                                  #
 # --------------------------------------------------------------------------- #
+def sample_negatives(indptr, indices, n_users, n_items, n_neg, seed, stream):
+    """CPU statement of the device sampler (tfrec_sample_negatives): (users, pos, neg[nnz, n_neg], n_full_rows)."""
+    L = lib()
+    L.oracle_sample_negatives.restype = C.c_int64
+    L.oracle_sample_negatives.argtypes = [_i64p, _i32p, C.c_int64, C.c_int64, C.c_int, C.c_uint64, C.c_uint64, _i32p, _i32p, _i32p]
+    indptr, indices = _c(indptr, np.int64), _c(indices, np.int32)
+    nnz = len(indices)
+    users, pos, neg = np.empty(nnz, np.int32), np.empty(nnz, np.int32), np.empty((nnz, n_neg), np.int32)
+    full = L.oracle_sample_negatives(indptr, indices, n_users, n_items, n_neg, seed, stream, users, pos, neg)
+    return users, pos, neg, int(full)
+
+
+def shuffle_perm(n, seed, stream):
+    """CPU statement of tfrec_shuffle_perm: stable argsort of the 32-bit hash keys."""
+    L = lib()
+    L.oracle_shuffle_keys.restype = None
+    L.oracle_shuffle_keys.argtypes = [C.c_int64, C.c_uint64, C.c_uint64, np.ctypeslib.ndpointer(np.uint32, flags="C")]
+    keys = np.empty(n, np.uint32)
+    L.oracle_shuffle_keys(n, seed, stream, keys)
+    return np.argsort(keys, kind="stable").astype(np.int32)
+
+
 def csr_to_user_dict(csr):
     """utils/tools.py:52-62 -- including its quirk: a row is kept only if ``any(indices)``
     is true, so empty rows AND rows whose only item id is 0 are dropped."""

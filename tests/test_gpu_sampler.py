@@ -1,0 +1,88 @@
+"""GPU tests of the device epoch pipeline (tfrec_sample_negatives, tfrec_shuffle_perm,
+tfrec_gather_rows_i32) against the CPU oracle: sampled indices and permutations are bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from tfrec_amd.device import Device
+    d = Device(0)
+    yield d
+    d.close()
+
+
+def _rows(rng, U, I, lo, hi):
+    rows = [np.sort(rng.choice(I, int(rng.integers(lo, hi + 1)), replace=False)).astype(np.int32) for _ in range(U)]
+    indptr = np.zeros(U + 1, np.int64)
+    indptr[1:] = np.cumsum([len(r) for r in rows])
+    return indptr, np.concatenate(rows)
+
+
+@pytest.mark.parametrize("U,I,lo,hi,n_neg", [(1000, 500, 0, 40, 1), (300, 64, 30, 63, 4), (5000, 20000, 1, 300, 1), (3, 7, 6, 6, 32)])
+def test_sampled_negatives_equal_the_oracle(dev, oracle, U, I, lo, hi, n_neg):
+    rng = np.random.default_rng(U + I)
+    indptr, indices = _rows(rng, U, I, lo, hi)
+    want = oracle.sample_negatives(indptr, indices, U, I, n_neg, 2018, 6)
+    u, p, n = dev.sample_negatives(dev.array(indptr, np.int64), dev.array(indices, np.int32), U, I, n_neg, 2018, 6)
+    dev.synchronize()
+    assert np.array_equal(u.numpy(), want[0]) and np.array_equal(p.numpy(), want[1]) and np.array_equal(n.numpy(), want[2])
+
+
+def test_ml100k_epoch_equals_the_oracle_and_full_rows_are_reported(dev, oracle, golden_ml100k):
+    from test_gpu_models import ml100k
+    tr = ml100k(golden_ml100k).train_matrix
+    from tfrec_amd.data import DeviceEpochSampler
+    s = DeviceEpochSampler(dev, tr, seed=2018)
+    for e in (0, 3):
+        u, p, n = s.epoch(e)
+        dev.synchronize()
+        wu, wp, wn, _ = oracle.sample_negatives(tr.indptr.astype(np.int64), tr.indices.astype(np.int32), 943, 1682, 1, 2018, 2 * e)
+        perm = oracle.shuffle_perm(tr.nnz, 2018, 2 * e + 1)
+        assert np.array_equal(u.numpy(), wu[perm]) and np.array_equal(p.numpy(), wp[perm]) and np.array_equal(n.numpy(), wn[perm])
+    # a user who holds every item: nothing can be drawn, the call is reported at synchronize
+    indptr = np.array([0, 2, 6], np.int64)
+    indices = np.array([1, 3, 0, 1, 2, 3], np.int32)
+    dev.sample_negatives(dev.array(indptr, np.int64), dev.array(indices, np.int32), 2, 4, 1, 1, 0)
+    with pytest.raises(IndexError):
+        dev.synchronize()
+    dev.synchronize()
+
+
+@pytest.mark.parametrize("n", [1, 63, 4097, 300000])
+def test_shuffle_and_gather_equal_the_oracle(dev, oracle, n):
+    perm = dev.shuffle_perm(n, 77, 5)
+    dev.synchronize()
+    want = oracle.shuffle_perm(n, 77, 5)
+    assert np.array_equal(perm.numpy(), want)
+    src = np.arange(3 * n, dtype=np.int32).reshape(n, 3) * 7
+    out = dev.gather_rows_i32(dev.array(src, np.int32), perm)
+    dev.synchronize()
+    assert np.array_equal(out.numpy(), src[want])
+
+
+def test_bpr_with_the_device_sampler_follows_the_oracle_schedule(dev, oracle, golden_ml100k):
+    """model BPR with ``sampler = device``: one epoch on ML-100k equals the oracle run over the
+    oracle-drawn, oracle-shuffled epoch."""
+    from test_gpu_models import ml100k, _Log
+    from tfrec_amd.evaluator import FoldOutEvaluator
+    from tfrec_amd.model import BPR
+    ds = ml100k(golden_ml100k)
+    ev = FoldOutEvaluator(ds.train_matrix, ds.test_matrix, top_k=50)
+    cfg = {"factors_num": 64, "lr": 0.01, "reg": 0.05, "epochs": 1, "batch_size": 512, "sampler": "device", "seed": 5}
+    BPR.logger = _Log()
+    model = BPR(dev, cfg, ds, ev)
+    P, Q, b = model.mf.parameters()
+    model.train_model()
+    tr = ds.train_matrix
+    u, p, n, _ = oracle.sample_negatives(tr.indptr.astype(np.int64), tr.indices.astype(np.int32), 943, 1682, 1, 5, 0)
+    perm = oracle.shuffle_perm(tr.nnz, 5, 1)
+    u, p, n = u[perm], p[perm], n[perm].ravel()
+    ws = oracle.Workspace(943, 1682, 64)
+    for lo in range(0, len(u), 512):
+        oracle.bpr_step(P, Q, b, u[lo:lo + 512], p[lo:lo + 512], n[lo:lo + 512], 0.01, 0.05, ws=ws)
+    P1, Q1, b1 = model.mf.parameters()
+    for a, c in ((P1, P), (Q1, Q), (b1, b)):
+        np.testing.assert_allclose(a, c, rtol=2e-4, atol=2e-6)

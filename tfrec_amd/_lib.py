@@ -17,6 +17,7 @@ _p = C.c_void_p
 _i64 = C.c_int64
 _int = C.c_int
 _f = C.c_float
+_u64 = C.c_uint64
 
 # name -> (restype, argtypes); one entry per symbol declared in include/tfrec_amd.h
 SIGNATURES = {
@@ -42,6 +43,9 @@ SIGNATURES = {
     "tfrec_fill_uniform_at": (_int, [_p, _p, _i64, _f, _f, C.c_uint64, _i64]),
     "tfrec_fill_const": (_int, [_p, _p, _i64, _f]),
     "tfrec_mf_predict": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _i64, _p]),
+    "tfrec_sample_negatives": (_int, [_p, _p, _p, _i64, _i64, _i64, _int, _u64, _u64, _p, _p, _p]),
+    "tfrec_shuffle_perm": (_int, [_p, _i64, _u64, _u64, _p]),
+    "tfrec_gather_rows_i32": (_int, [_p, _p, _i64, _p, _i64, _int, _p]),
     "tfrec_sort_pairs_u32": (_int, [_p, _p, _p, _p, _p, _i64, _int]),
     "tfrec_bpr_sgd_step": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _i64, _f, _f, _p]),
     "tfrec_batch_prepare": (_int, [_p, _int, _i64, _i64, _p, _p, _p, _i64]),

@@ -1,2 +1,3 @@
 from .dataiterator import DataIterator
 from .dataset import Dataset
+from .device_sampler import DeviceEpochSampler

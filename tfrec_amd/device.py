@@ -174,6 +174,34 @@ class Device:
         _lib.check(self.lib.tfrec_mf_predict(self.h, _ptr(P), _ptr(Q), _ptr(b), U, I, d, _ptr(users), _ptr(items), n, _ptr(out)))
         return out
 
+    # -- epoch pipeline ---------------------------------------------------------------------
+    def sample_negatives(self, indptr, indices, n_users, n_items, n_neg, seed, stream, users_out=None, pos_out=None, neg_out=None):
+        """Per stored interaction (CSR order): user, item and ``n_neg`` uniform draws from the items not
+        in the user's row (model/BPR.py:50-62, utils/tools.py:39-49).  Returns (users, pos, neg[nnz, n_neg])."""
+        nnz = _shape(indices)[0]
+        users_out = users_out if users_out is not None else self.empty(nnz, np.int32)
+        pos_out = pos_out if pos_out is not None else self.empty(nnz, np.int32)
+        neg_out = neg_out if neg_out is not None else self.empty((nnz, n_neg), np.int32)
+        _lib.check(self.lib.tfrec_sample_negatives(self.h, _ptr(indptr), _ptr(indices), int(n_users), int(n_items), nnz, int(n_neg),
+                                                   int(seed) & (2 ** 64 - 1), int(stream) & (2 ** 64 - 1), _ptr(users_out), _ptr(pos_out),
+                                                   _ptr(neg_out)))
+        return users_out, pos_out, neg_out
+
+    def shuffle_perm(self, n, seed, stream, out=None):
+        """A permutation of range(n), a pure function of (seed, stream, n) (data/dataiterator.py:52-54)."""
+        out = out if out is not None else self.empty(n, np.int32)
+        _lib.check(self.lib.tfrec_shuffle_perm(self.h, int(n), int(seed) & (2 ** 64 - 1), int(stream) & (2 ** 64 - 1), _ptr(out)))
+        return out
+
+    def gather_rows_i32(self, src, perm, out=None):
+        """out[r] = src[perm[r]] for an int32 array of rows."""
+        shp = _shape(src)
+        n = _shape(perm)[0]
+        width = int(np.prod(shp[1:])) if len(shp) > 1 else 1
+        out = out if out is not None else self.empty((n,) + tuple(shp[1:]), np.int32)
+        _lib.check(self.lib.tfrec_gather_rows_i32(self.h, _ptr(src), shp[0], _ptr(perm), n, width, _ptr(out)))
+        return out
+
     def sort_pairs(self, keys, vals, key_bits, out_keys=None, out_vals=None):
         """Stable sort of uint32 (key, value) pairs by the low ``key_bits`` bits of the key."""
         n = _shape(keys)[0]

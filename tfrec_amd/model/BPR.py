@@ -1,7 +1,7 @@
 """BPR-MF (Rendle et al.), with the reference's class shape (model/BPR.py:16-85)."""
 import numpy as np
 
-from ..data import DataIterator
+from ..data import DataIterator, DeviceEpochSampler
 from ..device import Device
 from ..utils import csr_to_user_dict, random_choice
 from .base import AbstractRecommender, MatrixFactorization
@@ -22,6 +22,13 @@ class BPR(AbstractRecommender):
         self.evaluator = evaluator
         self.sess = sess if sess is not None else Device(0)
         self.mf = MatrixFactorization(self.sess, self.users_num, self.items_num, self.factors_num, name=self.__class__.__name__)
+        # "sampler = device" (not a reference key): epochs are drawn and shuffled on the GPU; the default
+        # keeps the reference's host sampler and its numpy random stream
+        self.sampler = str(config["sampler"]).lower() if "sampler" in config else "host"
+        if self.sampler not in ("host", "device"):
+            raise ValueError("sampler must be 'host' or 'device'")
+        self._device_sampler = (DeviceEpochSampler(self.sess, train_matrix, seed=int(config["seed"]) if "seed" in config else 2018)
+                                if self.sampler == "device" else None)
 
     # -- sampling: uniform non-positive per positive, users in dict order (model/BPR.py:50-62) --
     def get_training_data(self):
@@ -46,10 +53,24 @@ class BPR(AbstractRecommender):
             dev.bpr_sgd_step(P, Q, b, du.view(lo, hi), dp.view(lo, hi), dn.view(lo, hi), self.lr, self.reg)
         dev.synchronize()
 
+    def _train_epoch_on_device(self, epoch):
+        """The same epoch with the triples drawn, shuffled and consumed on the GPU."""
+        dev = self.sess
+        users, pos, neg = self._device_sampler.epoch(epoch)
+        P, Q, b = self.mf.device_parameters()
+        n = self._device_sampler.nnz
+        for lo in range(0, n, self.batch_size):
+            hi = min(lo + self.batch_size, n)
+            dev.bpr_sgd_step(P, Q, b, users.view(lo, hi), pos.view(lo, hi), neg.view(lo, hi), self.lr, self.reg)
+        dev.synchronize()
+
     def train_model(self):
         self.logger.info(self.evaluator.metrics_info())
         for epoch in range(self.epochs):
-            self._train_epoch(self.get_training_data())
+            if self._device_sampler is not None:
+                self._train_epoch_on_device(epoch)
+            else:
+                self._train_epoch(self.get_training_data())
             result = self.evaluate_model()
             self.logger.info("epoch %d:\t%s" % (epoch, result))
 
