@@ -86,3 +86,33 @@ def test_bpr_with_the_device_sampler_follows_the_oracle_schedule(dev, oracle, go
     P1, Q1, b1 = model.mf.parameters()
     for a, c in ((P1, P), (Q1, Q), (b1, b)):
         np.testing.assert_allclose(a, c, rtol=2e-4, atol=2e-6)
+
+
+def test_dnsbpr_with_the_device_sampler_follows_the_oracle_schedule(dev, oracle, tmp_path, monkeypatch):
+    """DNS with ``sampler = device``: pools drawn on the GPU, arg-max under the current parameters,
+    shuffle, steps -- two epochs equal the oracle run (selected negatives exact, parameters 2e-4)."""
+    from test_gpu_models import synthetic, _Log
+    from tfrec_amd.evaluator import FoldOutEvaluator
+    from tfrec_amd.model import DNSBPR
+    monkeypatch.chdir(tmp_path)
+    ds = synthetic(4, U=150, I=120)
+    U, I = ds.train_matrix.shape
+    ev = FoldOutEvaluator(ds.train_matrix, ds.test_matrix, top_k=10)
+    cfg = {"factors_num": 32, "lr": 0.05, "reg": 0.01, "epochs": 2, "batch_size": 64, "neg_num": 8, "sampler": "device", "seed": 9,
+           "data_name": "synthetic"}
+    DNSBPR.logger = _Log()
+    model = DNSBPR(dev, cfg, ds, ev)
+    P, Q, b = model.mf.parameters()
+    model.train_model()
+    tr = ds.train_matrix
+    ws = oracle.Workspace(U, I, 32)
+    for e in range(2):
+        u, p, pools, _ = oracle.sample_negatives(tr.indptr.astype(np.int64), tr.indices.astype(np.int32), U, I, 8, 9, 2 * e)
+        n, _ = oracle.dns_select(P, Q, b, u, pools)
+        perm = oracle.shuffle_perm(tr.nnz, 9, 2 * e + 1)
+        u, p, n = u[perm], p[perm], n[perm]
+        for lo in range(0, len(u), 64):
+            oracle.bpr_step(P, Q, b, u[lo:lo + 64], p[lo:lo + 64], n[lo:lo + 64], 0.05, 0.01, ws=ws)
+    P1, Q1, b1 = model.mf.parameters()
+    for a, c in ((P1, P), (Q1, Q), (b1, b)):
+        np.testing.assert_allclose(a, c, rtol=2e-4, atol=2e-6)

@@ -53,10 +53,14 @@ class BPR(AbstractRecommender):
             dev.bpr_sgd_step(P, Q, b, du.view(lo, hi), dp.view(lo, hi), dn.view(lo, hi), self.lr, self.reg)
         dev.synchronize()
 
+    def _device_epoch(self, epoch):
+        """Device arrays (users, pos, neg) of the epoch, shuffled."""
+        return self._device_sampler.epoch(epoch)
+
     def _train_epoch_on_device(self, epoch):
         """The same epoch with the triples drawn, shuffled and consumed on the GPU."""
         dev = self.sess
-        users, pos, neg = self._device_sampler.epoch(epoch)
+        users, pos, neg = self._device_epoch(epoch)
         P, Q, b = self.mf.device_parameters()
         n = self._device_sampler.nnz
         for lo in range(0, n, self.batch_size):

@@ -1,7 +1,7 @@
 """BPR with dynamic negative sampling (model/DNSBPR.py:13-110)."""
 import numpy as np
 
-from ..data import DataIterator
+from ..data import DataIterator, DeviceEpochSampler
 from ..utils import random_choice, save_params
 from .BPR import BPR
 
@@ -11,6 +11,24 @@ class DNSBPR(BPR):
         super(DNSBPR, self).__init__(sess, config, dataset, evaluator)
         self.config = config
         self.neg_num = config["neg_num"]
+        if self._device_sampler is not None:      # pools of neg_num candidates per positive instead of one negative
+            self._device_sampler = DeviceEpochSampler(self.sess, dataset.train_matrix, seed=self._device_sampler.seed, n_neg=self.neg_num)
+            n = self._device_sampler.nnz
+            self._picked = self.sess.empty(n, np.int32)
+            self._picked_shuffled = self.sess.empty(n, np.int32)
+
+    def _device_epoch(self, epoch):
+        """The epoch of ``get_training_data`` without the host: candidate pools drawn on the GPU, the
+        best-scored candidate of every pool under the current parameters, then the shuffle."""
+        s, dev = self._device_sampler, self.sess
+        users, pos, pools = s.epoch(epoch, shuffle=False)
+        P, Q, b = self.mf.device_parameters()
+        dev.dns_select(P, Q, b, users, pools, out=self._picked)
+        perm = dev.shuffle_perm(s.nnz, s.seed, 2 * epoch + 1, out=s._perm)
+        dev.gather_rows_i32(users, perm, out=s.users)
+        dev.gather_rows_i32(pos, perm, out=s.pos)
+        dev.gather_rows_i32(self._picked, perm, out=self._picked_shuffled)
+        return s.users, s.pos, self._picked_shuffled
 
     def get_training_data(self):
         """For every positive draw ``neg_num`` uniform non-positives and keep the best-scored one
