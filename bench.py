@@ -311,6 +311,37 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": per_gpu, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per_gpu / HBM_PEAK_GBS,
                                "traffic": None, "kernel": "per GPU: one BPR step incl. the item-gradient exchange",
                                "algorithmic_bytes_per_triple": alg_bytes_per_triple}
+        if trainer is not None and not args.no_eval:
+            # item-sharded full-rank evaluation: every rank scores its item range for all evaluated users (their
+            # factors broadcast from the owner), lists all-gathered and merged; eval_users per GPU (weak scaling)
+            from tfrec_amd.sharded import ShardedEvaluator
+            g2 = torch.Generator(device=cuda)
+            g2.manual_seed(4242)                                   # the same interaction lists on every rank
+            n, k = min(args.eval_users * world, U), args.topk
+            eu = torch.arange(n, device=cuda, dtype=torch.int32)
+            deg, tdeg = 20, 3
+            indptr = torch.arange(0, deg * (U + 1), deg, device=cuda, dtype=torch.int64)
+            indices = torch.sort(torch.randint(0, I, (U, deg), device=cuda, generator=g2, dtype=torch.int32), dim=1).values.reshape(-1).contiguous()
+            tptr = torch.arange(0, tdeg * (U + 1), tdeg, device=cuda, dtype=torch.int64)
+            tidx = torch.sort(torch.randint(0, I, (U, tdeg), device=cuda, generator=g2, dtype=torch.int32), dim=1).values.reshape(-1).contiguous()
+            ev = {}
+            for mode, name in ((SCORE_F32, "f32"), (SCORE_BF16, "bf16")):
+                se = ShardedEvaluator(dev, trainer, (indptr, indices), (tptr, tidx), eu, top_k=k, mode=mode)
+                se.evaluate()                                      # warm-up, sizes the workspaces
+                barrier()
+                t1 = time.perf_counter()
+                se.evaluate()
+                barrier()
+                dt = time.perf_counter() - t1
+                if world > 1:
+                    tm = torch.tensor([dt], device=cuda, dtype=torch.float64)
+                    torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
+                    dt = float(tm.item())
+                tf = 2.0 * I * d * n / dt / 1e12
+                ev[name] = {"users_per_s": n / dt, "ms": dt * 1e3, "users": n, "items": I, "topk": k, "item_shards": world,
+                            "roofline": {"bound": "mfma", "achieved": tf / world, "peak": MFMA_PEAK_TFLOPS[name], "unit": "TFLOP/s per GPU",
+                                         "frac": tf / world / MFMA_PEAK_TFLOPS[name]}}
+            out["eval"] = ev
         if rank == 0 and world == 1 and not args.force_sharded:
             # ---- roofline of the step's kernels: HIP events recorded by the library on its own stream
             # (un-pipelined steps, so that the index phase is timed on the same stream as the row passes)
