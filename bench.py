@@ -312,13 +312,14 @@ def main():
                                "traffic": None, "kernel": "per GPU: one BPR step incl. the item-gradient exchange",
                                "algorithmic_bytes_per_triple": alg_bytes_per_triple}
         if trainer is not None and not args.no_eval:
-            # item-sharded full-rank evaluation: every rank scores its item range for all evaluated users (their
-            # factors broadcast from the owner), lists all-gathered and merged; eval_users per GPU (weak scaling)
+            # full-rank evaluation over the ranks, eval_users per GPU (weak scaling).  Replicated item table:
+            # every rank evaluates the users it owns against all items.  Sharded item table: every rank scores
+            # its item range for all evaluated users (factors broadcast from the owner), lists gathered and merged.
             from tfrec_amd.sharded import ShardedEvaluator
             g2 = torch.Generator(device=cuda)
             g2.manual_seed(4242)                                   # the same interaction lists on every rank
             n, k = min(args.eval_users * world, U), args.topk
-            eu = torch.arange(n, device=cuda, dtype=torch.int32)
+            eu = (torch.arange(n, device=cuda, dtype=torch.int64) * U // n).to(torch.int32)     # spread evenly over the owners
             deg, tdeg = 20, 3
             indptr = torch.arange(0, deg * (U + 1), deg, device=cuda, dtype=torch.int64)
             indices = torch.sort(torch.randint(0, I, (U, deg), device=cuda, generator=g2, dtype=torch.int32), dim=1).values.reshape(-1).contiguous()
@@ -338,7 +339,7 @@ def main():
                     torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
                     dt = float(tm.item())
                 tf = 2.0 * I * d * n / dt / 1e12
-                ev[name] = {"users_per_s": n / dt, "ms": dt * 1e3, "users": n, "items": I, "topk": k, "item_shards": world,
+                ev[name] = {"users_per_s": n / dt, "ms": dt * 1e3, "users": n, "items": I, "topk": k, "layout": se.layout + "-sharded",
                             "roofline": {"bound": "mfma", "achieved": tf / world, "peak": MFMA_PEAK_TFLOPS[name], "unit": "TFLOP/s per GPU",
                                          "frac": tf / world / MFMA_PEAK_TFLOPS[name]}}
             out["eval"] = ev

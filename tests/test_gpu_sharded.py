@@ -86,9 +86,11 @@ def _two_rank_worker(rank, world, port, out_dir):
     eidx = torch.from_numpy(np.sort(rng.integers(0, I, (U, 2)), axis=1).astype(np.int32).ravel()).to(cuda)
     users = torch.arange(0, U, 5, dtype=torch.int32, device=cuda)
     m = ShardedEvaluator(dev, tr, (tptr, tidx), (eptr, eidx), users, top_k=k, chunk_users=300).evaluate()
+    m_items = ShardedEvaluator(dev, tr, (tptr, tidx), (eptr, eidx), users, top_k=k, chunk_users=300, layout="items").evaluate()
     dev.synchronize()
     if rank == 0:
-        np.savez(os.path.join(out_dir, "two.npz"), P=P.cpu().numpy(), Q=Q.cpu().numpy(), b=b.cpu().numpy(), m=m.cpu().numpy())
+        np.savez(os.path.join(out_dir, "two.npz"), P=P.cpu().numpy(), Q=Q.cpu().numpy(), b=b.cpu().numpy(), m=m.cpu().numpy(),
+                 m_items=m_items.cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
     dev.close()
@@ -125,5 +127,6 @@ def test_two_ranks_dense_mode_match_one_rank(tmp_path):
     P2, Q2, b2 = dev.array(r["P"]), dev.array(r["Q"]), dev.array(r["b"])
     ref = dev.eval_fullrank(P2, Q2, b2, dev.array(users, np.int32), (dev.array(tptr, np.int64), dev.array(tidx, np.int32)),
                             (dev.array(eptr, np.int64), dev.array(eidx, np.int32)), k, mean_mode=0)
-    np.testing.assert_allclose(r["m"], ref, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(r["m"], ref, rtol=1e-6, atol=1e-7)            # user-sharded (replicated item table)
+    np.testing.assert_allclose(r["m_items"], ref, rtol=1e-6, atol=1e-7)      # item-sharded: local top-k, gather, merge
     dev.close()

@@ -19,6 +19,8 @@ Layout
     of the shape of [Q | b]; one all-reduce sums the tables; every rank applies the same update to
     its copy.  No host synchronisation, one collective per step.  For evaluation each rank scores
     its own item range of the copy, as in the sharded layout.
+  * evaluation with the replicated item table: user-sharded -- every rank evaluates the users it owns
+    against all items, only the metric sums are all-reduced.
   * evaluation: item-sharded.  The factor rows of a chunk of evaluated users are broadcast from
     their owner, every rank takes the top-k over its own items (global ids), the lists are
     all-gathered and merged under the total order (score desc, id asc) -- so the result is that
@@ -264,12 +266,22 @@ class ShardedEvaluator:
     tensors over ALL users on this rank's device (replicated); ``test_users`` the sorted global ids
     of the users to evaluate (replicated)."""
 
-    def __init__(self, dev_or_backend, trainer, train, test, test_users, top_k=50, mode=0, chunk_users=1 << 18):
+    def __init__(self, dev_or_backend, trainer, train, test, test_users, top_k=50, mode=0, chunk_users=1 << 18, layout="auto"):
         self.backend = dev_or_backend if hasattr(dev_or_backend, "metric_sums") else HipBackend(dev_or_backend)
         self.t = trainer
         self.train, self.test = train, test
         self.test_users = test_users.to(torch.int32)
         self.k, self.mode, self.chunk = int(top_k), int(mode), int(chunk_users)
+        # "items": every rank scores its item range for all users, lists gathered and merged (the only
+        # choice when the item table is sharded).  "users": with a replicated item table every rank
+        # evaluates the users it owns against all items -- no exchange but the final sum.
+        if layout == "auto":
+            layout = "users" if getattr(trainer, "item_mode", "sharded") == "dense" else "items"
+        if layout not in ("items", "users"):
+            raise ValueError("layout must be 'auto', 'items' or 'users'")
+        if layout == "users" and getattr(trainer, "item_mode", "sharded") != "dense":
+            raise ValueError("user-sharded evaluation needs the replicated item table")
+        self.layout = layout
 
     def _gather_lists(self, x):
         """[n, k] per rank -> [world, n, k] on every rank (800 bytes per user and rank at k=100)."""
@@ -281,8 +293,27 @@ class ShardedEvaluator:
         dist.all_gather(outs, x.contiguous(), group=t.group)
         return torch.stack(outs)
 
+    def _evaluate_own_users(self):
+        t, k = self.t, self.k
+        sums = torch.zeros(5 * k, dtype=torch.float64, device=t.device)
+        tu = self.test_users.to(torch.int64)
+        own = self.test_users[(tu >= t.user_range[0]) & (tu < t.user_range[1])]
+        for s in range(0, own.shape[0], self.chunk):
+            eu = own[s:s + self.chunk].contiguous()
+            rows = t.P.index_select(0, eu.to(torch.int64) - t.user_range[0]).contiguous()
+            ids, _ = self.backend.score_topk_shard(rows, t.Q_full, t.b_full, 0, eu, k, self.train, self.mode)
+            if self.train is not None:
+                self.backend.fill_masked(ids, eu, k, self.train)
+            sums += self.backend.metric_sums(ids, eu, k, self.test)
+        if t.world > 1:
+            _drain_for_gloo(sums, t.group)
+            dist.all_reduce(sums, group=t.group)
+        return (sums / float(self.test_users.shape[0])).to(torch.float32).reshape(5, k)
+
     def evaluate(self):
         """float32 [5, k] on every rank: Precision, Recall, MAP, NDCG, MRR @1..k."""
+        if self.layout == "users":
+            return self._evaluate_own_users()
         t, k, W = self.t, self.k, self.t.world
         dev = t.device
         sums = torch.zeros(5 * k, dtype=torch.float64, device=dev)
