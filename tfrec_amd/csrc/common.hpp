@@ -91,7 +91,7 @@ int tfrec_pinned_require(tfrec_ctx *ctx, size_t bytes);
 
 static inline size_t tf_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
-// rocPRIM-backed stable LSD radix sort of (key,value) pairs (sort.hip)
+// stable LSD radix sort of (key,value) pairs (sort.hip)
 size_t tfrec_sort_temp_bytes(size_t n, int end_bit);
 int tfrec_sort_pairs(void *d_temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
                      const uint32_t *vals_in, uint32_t *vals_out, size_t n, int end_bit, hipStream_t stream);
