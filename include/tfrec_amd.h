@@ -108,10 +108,14 @@ int tfrec_sort_pairs_u32(tfrec_ctx *ctx, const uint32_t *d_keys_in, const uint32
  * ascending) writes its user, its item and n_neg items drawn uniformly, with replacement, from the
  * items NOT in the user's row (rejection against the row).  The random numbers are a counter-based
  * hash of (seed, stream, t * n_neg + c, attempt) -- not numpy's stream, which cannot be drawn in
- * parallel -- so the output is a pure function of the arguments.  d_users_out / d_pos_out may be
- * null.  A user who holds every item raises the bad-index flag (TFREC_EINDEX at synchronize). */
+ * parallel -- so the output is a pure function of the arguments.  first_interaction is the position
+ * of this matrix's first stored interaction in the whole training set (0 for the whole matrix): a
+ * shard of user rows then draws exactly what the whole matrix draws for those rows.  d_users_out
+ * (row numbers of THIS matrix) / d_pos_out may be null.  A user who holds every item raises the
+ * bad-index flag (TFREC_EINDEX at synchronize). */
 int tfrec_sample_negatives(tfrec_ctx *ctx, const int64_t *d_indptr, const int32_t *d_indices,
                            int64_t U, int64_t I, int64_t nnz, int n_neg, uint64_t seed, uint64_t stream,
+                           int64_t first_interaction,
                            int32_t *d_users_out, int32_t *d_pos_out, int32_t *d_neg_out);
 /* A permutation of 0..n-1 that is a pure function of (seed, stream, n): stable sort of 32-bit hash
  * keys (the shuffle of data/dataiterator.py:52-54). */

@@ -466,7 +466,7 @@ static int o_row_contains(const int32_t *idx, int64_t lo, int64_t hi, int32_t id
 }
 /* returns the number of users whose row holds every item (nothing to draw; their negatives are 0) */
 int64_t oracle_sample_negatives(const int64_t *indptr, const int32_t *indices, int64_t U, int64_t I, int n_neg, uint64_t seed,
-                                uint64_t stream, int32_t *users_out, int32_t *pos_out, int32_t *neg_out)
+                                uint64_t stream, int64_t first, int32_t *users_out, int32_t *pos_out, int32_t *neg_out)
 {
     int64_t n_full = 0;
     for (int64_t u = 0; u < U; ++u) {
@@ -477,7 +477,8 @@ int64_t oracle_sample_negatives(const int64_t *indptr, const int32_t *indices, i
             users_out[t] = (int32_t)u;
             pos_out[t] = indices[t];
             for (int c = 0; c < n_neg; ++c) {
-                const uint64_t index = (uint64_t)t * (uint64_t)n_neg + (uint64_t)c;
+                const uint64_t slot = (uint64_t)t * (uint64_t)n_neg + (uint64_t)c;
+                const uint64_t index = ((uint64_t)first + (uint64_t)t) * (uint64_t)n_neg + (uint64_t)c;
                 uint32_t cand = 0;
                 if (!full) {
                     int ok = 0;
@@ -490,7 +491,7 @@ int64_t oracle_sample_negatives(const int64_t *indptr, const int32_t *indices, i
                         ok = !o_row_contains(indices, r0, r1, (int32_t)cand);
                     }
                 }
-                neg_out[index] = (int32_t)cand;
+                neg_out[slot] = (int32_t)cand;
             }
         }
     }

@@ -185,15 +185,15 @@ def eval_dense(R, train_dict, test_dict, k):
 # --------------------------------------------------------------------------- #
 # host-side sampling / batching restatements                                  #
 # --------------------------------------------------------------------------- #
-def sample_negatives(indptr, indices, n_users, n_items, n_neg, seed, stream):
+def sample_negatives(indptr, indices, n_users, n_items, n_neg, seed, stream, first=0):
     """CPU statement of the device sampler (tfrec_sample_negatives): (users, pos, neg[nnz, n_neg], n_full_rows)."""
     L = lib()
     L.oracle_sample_negatives.restype = C.c_int64
-    L.oracle_sample_negatives.argtypes = [_i64p, _i32p, C.c_int64, C.c_int64, C.c_int, C.c_uint64, C.c_uint64, _i32p, _i32p, _i32p]
+    L.oracle_sample_negatives.argtypes = [_i64p, _i32p, C.c_int64, C.c_int64, C.c_int, C.c_uint64, C.c_uint64, C.c_int64, _i32p, _i32p, _i32p]
     indptr, indices = _c(indptr, np.int64), _c(indices, np.int32)
     nnz = len(indices)
     users, pos, neg = np.empty(nnz, np.int32), np.empty(nnz, np.int32), np.empty((nnz, n_neg), np.int32)
-    full = L.oracle_sample_negatives(indptr, indices, n_users, n_items, n_neg, seed, stream, users, pos, neg)
+    full = L.oracle_sample_negatives(indptr, indices, n_users, n_items, n_neg, seed, stream, first, users, pos, neg)
     return users, pos, neg, int(full)
 
 

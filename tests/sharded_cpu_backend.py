@@ -49,6 +49,20 @@ class CpuBackend:
         y_, x_ = _np(y), _np(x)
         y_[:] = (y_.astype(np.float64) + alpha * x_.astype(np.float64)).astype(np.float32)
 
+    def sample_negatives(self, indptr, indices, n_users, n_items, n_neg, seed, stream, first):
+        u, p, n, _ = orc.sample_negatives(_np(indptr), _np(indices), n_users, n_items, n_neg, seed, stream, first)
+        return torch.from_numpy(u), torch.from_numpy(p), torch.from_numpy(n)
+
+    def dns_select(self, P, Q, b, users, cand):
+        sel, _ = orc.dns_select(_np(P), np.ascontiguousarray(_np(Q)), np.ascontiguousarray(_np(b)), _np(users), _np(cand))
+        return torch.from_numpy(sel.astype(np.int32))
+
+    def shuffle_perm(self, n, seed, stream, device):
+        return torch.from_numpy(orc.shuffle_perm(n, seed, stream))
+
+    def gather_rows(self, src, perm):
+        return src[perm.to(torch.int64)].contiguous()
+
     def rows_sgd_apply(self, Q, b, ids, grad_rows, grad_b, lr):
         Q_, b_ = _np(Q), _np(b)
         g = np.zeros(Q_.shape); gb = np.zeros(b_.shape)

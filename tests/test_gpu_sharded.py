@@ -130,3 +130,40 @@ def test_two_ranks_dense_mode_match_one_rank(tmp_path):
     np.testing.assert_allclose(r["m"], ref, rtol=1e-6, atol=1e-7)            # user-sharded (replicated item table)
     np.testing.assert_allclose(r["m_items"], ref, rtol=1e-6, atol=1e-7)      # item-sharded: local top-k, gather, merge
     dev.close()
+
+
+@pytest.mark.parametrize("item_mode", ["dense", "sharded"])
+def test_sharded_epoch_sampler_on_the_gpu(oracle, item_mode):
+    """ShardedEpochSampler with the HIP backend (one rank): DNS pools, picks and one collective epoch
+    equal the oracle's statement of the same epoch."""
+    import scipy.sparse as sp
+    from tfrec_amd.sharded import ShardedBprTrainer, ShardedEpochSampler, make_device
+    dev = make_device(0)
+    U, I, d, C, B = 400, 300, 32, 6, 256
+    rng = np.random.default_rng(2)
+    rows, cols = [], []
+    for u in range(U):
+        c = rng.permutation(I)[: int(rng.integers(0, 12))]
+        rows += [u] * len(c); cols += c.tolist()
+    m = sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(U, I)); m.sort_indices()
+    tr = ShardedBprTrainer(dev, U, I, d, 0.05, 0.01, seed=3, item_mode=item_mode)
+    P, Q, b = [x.cpu().numpy().copy() for x in tr.gather_full()]
+    s = ShardedEpochSampler(dev, tr, m, seed=17, n_neg=C)
+    u, p, n = [x.cpu().numpy() for x in s.draw(0)]
+    wu, wp, pools, _ = oracle.sample_negatives(m.indptr.astype(np.int64), m.indices.astype(np.int32), U, I, C, 17, 0)
+    want, margin = oracle.dns_select(P, Q, b, wu, pools)
+    assert np.array_equal(u, wu) and np.array_equal(p, wp)
+    ok = margin > 1e-6
+    assert ok.mean() > 0.9 and np.array_equal(n[ok], want[ok])
+    eu, ep, en = [x.cpu().numpy() for x in s.epoch(0)]
+    perm = oracle.shuffle_perm(m.nnz, 17, 1)
+    assert np.array_equal(eu, u[perm]) and np.array_equal(ep, p[perm]) and np.array_equal(en, n[perm])
+    steps = s.train_epoch(0, B)
+    assert steps == (m.nnz + B - 1) // B
+    ws = oracle.Workspace(U, I, d)
+    for lo in range(0, m.nnz, B):
+        oracle.bpr_step(P, Q, b, eu[lo:lo + B], ep[lo:lo + B], en[lo:lo + B], 0.05, 0.01, ws=ws)
+    P1, Q1, b1 = [x.cpu().numpy() for x in tr.gather_full()]
+    for a, c in ((P1, P), (Q1, Q), (b1, b)):
+        np.testing.assert_allclose(a, c, rtol=1e-4, atol=1e-6)
+    dev.close()

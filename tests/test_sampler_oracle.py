@@ -67,3 +67,16 @@ def test_shuffle_is_a_reproducible_permutation(oracle):
     # no position is favoured: mean displacement of a uniform permutation is n/3
     p = oracle.shuffle_perm(70001, 9, 3).astype(np.int64)
     assert abs(np.abs(p - np.arange(70001)).mean() / 70001 - 1 / 3) < 0.01
+
+
+def test_row_shards_draw_what_the_whole_matrix_draws(oracle):
+    rng = np.random.default_rng(3)
+    U, I = 200, 150
+    indptr, indices, _ = _rows(rng, U, I, 0, 30)
+    _, _, whole, _ = oracle.sample_negatives(indptr, indices, U, I, 4, 8, 2)
+    for lo, hi in ((0, 70), (70, 71), (71, 200)):
+        sub_ptr = (indptr[lo:hi + 1] - indptr[lo]).astype(np.int64)
+        sub_idx = indices[indptr[lo]:indptr[hi]]
+        u, p, n, _ = oracle.sample_negatives(sub_ptr, sub_idx, hi - lo, I, 4, 8, 2, first=int(indptr[lo]))
+        assert np.array_equal(n, whole[indptr[lo]:indptr[hi]])
+        assert np.array_equal(u, np.repeat(np.arange(hi - lo), np.diff(sub_ptr)).astype(np.int32))

@@ -44,7 +44,7 @@ constexpr int SAMPLE_TRIES = 64;
 // span (two whole-array searches per workgroup, a few steps per thread).
 __global__ __launch_bounds__(256) void sample_negatives_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                                                                int64_t U, uint32_t I, int64_t n, int C, uint64_t seed, uint64_t stream,
-                                                               int32_t *__restrict__ users_out, int32_t *__restrict__ pos_out,
+                                                               uint64_t first, int32_t *__restrict__ users_out, int32_t *__restrict__ pos_out,
                                                                int32_t *__restrict__ neg_out, uint32_t *__restrict__ flags)
 {
     __shared__ int64_t row_range[2];
@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(const int64_t *__
     const bool full = (uint64_t)(r1 - r0) >= (uint64_t)I;      // no item left to draw: reported, never loops
     if (full) atomicOr(flags, TFREC_FLAG_BAD_INDEX);
     for (int c = 0; c < C; ++c) {
-        const uint64_t index = (uint64_t)t * (uint64_t)C + (uint64_t)c;
+        const uint64_t slot = (uint64_t)t * (uint64_t)C + (uint64_t)c;        // where the draw is written
+        const uint64_t index = (first + (uint64_t)t) * (uint64_t)C + (uint64_t)c;  // which draw it is
         uint32_t cand = 0;
         if (!full) {
             bool ok = false;
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(const int64_t *__
                 ok = !row_contains(indices, r0, r1, (int32_t)cand);
             }
         }
-        neg_out[index] = (int32_t)cand;
+        neg_out[slot] = (int32_t)cand;
     }
 }
 
@@ -114,16 +115,16 @@ __global__ __launch_bounds__(256) void gather_rows_i32_kernel(const int32_t *__r
 }  // namespace
 
 extern "C" int tfrec_sample_negatives(tfrec_ctx *ctx, const int64_t *d_indptr, const int32_t *d_indices, int64_t U, int64_t I,
-                                      int64_t nnz, int n_neg, uint64_t seed, uint64_t stream, int32_t *d_users_out,
-                                      int32_t *d_pos_out, int32_t *d_neg_out)
+                                      int64_t nnz, int n_neg, uint64_t seed, uint64_t stream, int64_t first_interaction,
+                                      int32_t *d_users_out, int32_t *d_pos_out, int32_t *d_neg_out)
 {
     TF_TRY(tfrec_ctx_enter(ctx));
     TF_REQUIRE(U > 0 && I > 0 && I < (1ll << 31) && U < (1ll << 31), TFREC_EINVAL, "bad shape U=%lld I=%lld", (long long)U, (long long)I);
-    TF_REQUIRE(nnz >= 0 && n_neg >= 1, TFREC_EINVAL, "bad interaction count or negatives per positive");
+    TF_REQUIRE(nnz >= 0 && n_neg >= 1 && first_interaction >= 0, TFREC_EINVAL, "bad interaction count, offset or negatives per positive");
     if (nnz == 0) return TFREC_OK;
     TF_REQUIRE(d_indptr && d_indices && d_neg_out, TFREC_EINVAL, "null array");
     sample_negatives_kernel<<<(unsigned)((nnz + 255) / 256), 256, 0, ctx->stream>>>(d_indptr, d_indices, U, (uint32_t)I, nnz, n_neg, seed,
-                                                                                  stream, d_users_out, d_pos_out, d_neg_out, ctx->d_flags);
+                                                                                  stream, (uint64_t)first_interaction, d_users_out, d_pos_out, d_neg_out, ctx->d_flags);
     TF_HIP(hipGetLastError());
     return TFREC_OK;
 }

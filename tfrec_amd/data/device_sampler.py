@@ -10,7 +10,7 @@ import numpy as np
 
 
 class DeviceEpochSampler:
-    def __init__(self, dev, train_matrix, seed=2018, n_neg=1):
+    def __init__(self, dev, train_matrix, seed=2018, n_neg=1, first_interaction=0):
         csr = train_matrix.tocsr()
         csr.sort_indices()
         self.dev = dev
@@ -18,6 +18,7 @@ class DeviceEpochSampler:
         self.nnz = int(csr.nnz)
         self.n_neg = int(n_neg)
         self.seed = int(seed)
+        self.first_interaction = int(first_interaction)    # position of row 0's first interaction in the whole set (row shards)
         self.indptr = dev.array(csr.indptr.astype(np.int64), np.int64)
         self.indices = dev.array(csr.indices.astype(np.int32), np.int32)
         # outputs in storage order, reused every epoch; shuffled copies are what the steps read
@@ -34,7 +35,7 @@ class DeviceEpochSampler:
         Streams 2e and 2e+1 of the seed feed the draws and the shuffle."""
         dev = self.dev
         dev.sample_negatives(self.indptr, self.indices, self.n_users, self.n_items, self.n_neg, self.seed, 2 * e,
-                             users_out=self._users, pos_out=self._pos, neg_out=self._neg)
+                             users_out=self._users, pos_out=self._pos, neg_out=self._neg, first_interaction=self.first_interaction)
         if not shuffle:
             return self._users, self._pos, self._neg
         dev.shuffle_perm(self.nnz, self.seed, 2 * e + 1, out=self._perm)

@@ -175,16 +175,18 @@ class Device:
         return out
 
     # -- epoch pipeline ---------------------------------------------------------------------
-    def sample_negatives(self, indptr, indices, n_users, n_items, n_neg, seed, stream, users_out=None, pos_out=None, neg_out=None):
+    def sample_negatives(self, indptr, indices, n_users, n_items, n_neg, seed, stream, users_out=None, pos_out=None, neg_out=None,
+                         first_interaction=0):
         """Per stored interaction (CSR order): user, item and ``n_neg`` uniform draws from the items not
-        in the user's row (model/BPR.py:50-62, utils/tools.py:39-49).  Returns (users, pos, neg[nnz, n_neg])."""
+        in the user's row (model/BPR.py:50-62, utils/tools.py:39-49).  Returns (users, pos, neg[nnz, n_neg]).
+        ``first_interaction``: position of this matrix's first interaction in the whole training set (row shards)."""
         nnz = _shape(indices)[0]
         users_out = users_out if users_out is not None else self.empty(nnz, np.int32)
         pos_out = pos_out if pos_out is not None else self.empty(nnz, np.int32)
         neg_out = neg_out if neg_out is not None else self.empty((nnz, n_neg), np.int32)
         _lib.check(self.lib.tfrec_sample_negatives(self.h, _ptr(indptr), _ptr(indices), int(n_users), int(n_items), nnz, int(n_neg),
-                                                   int(seed) & (2 ** 64 - 1), int(stream) & (2 ** 64 - 1), _ptr(users_out), _ptr(pos_out),
-                                                   _ptr(neg_out)))
+                                                   int(seed) & (2 ** 64 - 1), int(stream) & (2 ** 64 - 1), int(first_interaction),
+                                                   _ptr(users_out), _ptr(pos_out), _ptr(neg_out)))
         return users_out, pos_out, neg_out
 
     def shuffle_perm(self, n, seed, stream, out=None):

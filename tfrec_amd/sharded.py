@@ -72,6 +72,30 @@ class HipBackend:
     def axpy(self, y, x, alpha):
         self.dev.axpy(y, x, alpha)
 
+    def sample_negatives(self, indptr, indices, n_users, n_items, n_neg, seed, stream, first):
+        nnz = indices.shape[0]
+        u = torch.empty(nnz, dtype=torch.int32, device=indices.device)
+        p = torch.empty(nnz, dtype=torch.int32, device=indices.device)
+        n = torch.empty((nnz, n_neg), dtype=torch.int32, device=indices.device)
+        self.dev.sample_negatives(indptr, indices, n_users, n_items, n_neg, seed, stream, users_out=u, pos_out=p, neg_out=n,
+                                  first_interaction=first)
+        return u, p, n
+
+    def dns_select(self, P, Q, b, users, cand):
+        out = torch.empty(users.shape[0], dtype=torch.int32, device=users.device)
+        self.dev.dns_select(P, Q, b, users, cand, out=out)
+        return out
+
+    def shuffle_perm(self, n, seed, stream, device):
+        out = torch.empty(n, dtype=torch.int32, device=device)
+        self.dev.shuffle_perm(n, seed, stream, out=out)
+        return out
+
+    def gather_rows(self, src, perm):
+        out = torch.empty((perm.shape[0],) + tuple(src.shape[1:]), dtype=torch.int32, device=src.device)
+        self.dev.gather_rows_i32(src.contiguous(), perm, out=out)
+        return out
+
     def score_topk_shard(self, P_rows, Q, b, item_lo, users, k, train, mode):
         n = P_rows.shape[0]
         ids = torch.empty((n, k), dtype=torch.int32, device=P_rows.device)
@@ -244,6 +268,23 @@ class ShardedBprTrainer:
             self.backend.rows_sgd_apply(self.Q, self.b, local.to(torch.int32).contiguous(), grads[:, :self.d].contiguous(),
                                         grads[:, self.d].contiguous(), self.lr)
 
+    def full_item_table(self):
+        """(Q, b) of ALL items on this rank: the local copy (replicated table) or an all-gather of the
+        shards (collective).  Read-only use, e.g. the epoch-start candidate scoring of DNS."""
+        if self.item_mode == "dense":
+            return self.Q_full, self.b_full
+        if self.world == 1:
+            return self.Q, self.b
+
+        def cat(x):
+            pad = torch.zeros((self.ipr,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+            pad[: x.shape[0]] = x
+            outs = [torch.empty_like(pad) for _ in range(self.world)]
+            _drain_for_gloo(pad, self.group)
+            dist.all_gather(outs, pad, group=self.group)
+            return torch.cat(outs)[: self.I].contiguous()
+        return cat(self.Q), cat(self.b)
+
     def gather_full(self):
         """(P, Q, b) assembled on every rank (testing / checkpointing)."""
         def cat(x, n):
@@ -341,3 +382,65 @@ class ShardedEvaluator:
             _drain_for_gloo(sums, t.group)
             dist.all_reduce(sums, group=t.group)
         return (sums / float(self.test_users.shape[0])).to(torch.float32).reshape(5, k)
+
+
+class ShardedEpochSampler:
+    """Epochs of triples for a ``ShardedBprTrainer``, drawn on every rank for the users it owns
+    (model/BPR.py:50-62; with ``n_neg > 1`` the dynamic negative sampling of model/DNSBPR.py:65-80:
+    pools of ``n_neg`` candidates per positive, the best-scored one under the parameters at the
+    start of the epoch).  A rank's draws are those the whole training matrix would draw for its rows
+    (the draw counter is the global position of the interaction), so the sampled triples do not
+    depend on the number of ranks; each rank shuffles its own triples."""
+
+    def __init__(self, dev_or_backend, trainer, train_matrix, seed=2018, n_neg=1):
+        self.backend = dev_or_backend if hasattr(dev_or_backend, "uniform_rows") else HipBackend(dev_or_backend)
+        self.t = trainer
+        csr = train_matrix.tocsr()
+        csr.sort_indices()
+        lo, hi = trainer.user_range
+        self.first = int(csr.indptr[lo])
+        sub = csr[lo:hi]
+        dev = trainer.device
+        self.indptr = torch.from_numpy(sub.indptr.astype(np.int64)).to(dev)
+        self.indices = torch.from_numpy(sub.indices.astype(np.int32)).to(dev)
+        self.nnz = int(sub.nnz)
+        self.n_neg, self.seed = int(n_neg), int(seed)
+
+    def draw(self, e):
+        """(local user rows, items, negatives) of epoch ``e`` in storage order; collective when the item
+        table is sharded and ``n_neg > 1`` (the candidates are scored against all items)."""
+        t, be = self.t, self.backend
+        nu = t.user_range[1] - t.user_range[0]
+        if self.nnz > 0:
+            u, p, cand = be.sample_negatives(self.indptr, self.indices, nu, t.I, self.n_neg, self.seed, 2 * e, self.first)
+        else:
+            u = torch.empty(0, dtype=torch.int32, device=t.device); p = u.clone()
+            cand = torch.empty((0, self.n_neg), dtype=torch.int32, device=t.device)
+        if self.n_neg == 1:
+            return u, p, cand.reshape(-1)
+        Qf, bf = t.full_item_table()
+        neg = be.dns_select(t.P, Qf, bf, u, cand) if self.nnz > 0 else u.clone()
+        return u, p, neg
+
+    def epoch(self, e):
+        """Shuffled (users as GLOBAL ids, items, negatives) of this rank for epoch ``e``."""
+        u, p, n = self.draw(e)
+        if self.nnz == 0:
+            return u, p, n
+        perm = self.backend.shuffle_perm(self.nnz, self.seed, (2 * e + 1) + (self.t.rank << 40), self.t.device)
+        be = self.backend
+        return be.gather_rows(u, perm) + self.t.user_range[0], be.gather_rows(p, perm), be.gather_rows(n, perm)
+
+    def train_epoch(self, e, batch_size):
+        """One epoch of collective steps: every rank feeds ``batch_size`` of its own triples per step;
+        ranks that run out keep stepping with empty batches until the longest list is consumed."""
+        t = self.t
+        users, pos, neg = self.epoch(e)
+        steps = torch.tensor([(self.nnz + batch_size - 1) // batch_size], dtype=torch.int64, device=t.device)
+        if t.world > 1:
+            _drain_for_gloo(steps, t.group)
+            dist.all_reduce(steps, op=dist.ReduceOp.MAX, group=t.group)
+        for s in range(int(steps.item())):
+            lo, hi = min(s * batch_size, self.nnz), min((s + 1) * batch_size, self.nnz)
+            t.step(users[lo:hi], pos[lo:hi], neg[lo:hi])
+        return int(steps.item())
