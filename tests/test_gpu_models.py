@@ -166,10 +166,12 @@ def test_apr_epoch_matches_the_oracle_schedule(dev, oracle, tmp_path):
         np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-6)
 
 
-def test_run_model_end_to_end(tmp_path):
-    """run_model.py with the shipped ini layout: one epoch of BPR on ML-100k, one log line of 250 numbers."""
+@pytest.mark.parametrize("extra", ["", "sampler = device\n"])
+def test_run_model_end_to_end(tmp_path, extra):
+    """run_model.py with the shipped ini layout: one epoch of BPR on ML-100k, one log line of 250 numbers
+    (also with the epoch drawn on the GPU: ``sampler = device`` in the model's ini)."""
     os.makedirs(tmp_path / "conf")
-    (tmp_path / "conf" / "BPR.ini").write_text("[hyperparameters]\nlr = 0.01\nreg = 0.05\nfactors_num = 20\nbatch_size = 512\nepochs = 1\n")
+    (tmp_path / "conf" / "BPR.ini").write_text("[hyperparameters]\nlr = 0.01\nreg = 0.05\nfactors_num = 20\nbatch_size = 512\nepochs = 1\n" + extra)
     ini = open(os.path.join(ROOT, "tfrec.ini")).read().replace("./dataset/", os.path.join(ROOT, "dataset") + "/")
     (tmp_path / "tfrec.ini").write_text(ini)
     if not os.path.exists(os.path.join(ROOT, "dataset", "movielens-100k-train.txt")):
@@ -182,3 +184,4 @@ def test_run_model_end_to_end(tmp_path):
     assert len(vals) == 250 and 0.0 < vals[0] <= 1.0
     logs = os.listdir(tmp_path / "log" / "ml100k" / "BPR")
     assert len(logs) == 1 and logs[0].startswith("BPR_log_lr=0.01_reg=0.05_factors_num=20_batch_size=512_epochs=1_")
+    assert ("sampler=device" in logs[0]) == bool(extra)
