@@ -343,6 +343,32 @@ def main():
                             "roofline": {"bound": "mfma", "achieved": tf / world, "peak": MFMA_PEAK_TFLOPS[name], "unit": "TFLOP/s per GPU",
                                          "frac": tf / world / MFMA_PEAK_TFLOPS[name]}}
             out["eval"] = ev
+        if trainer is not None and not args.no_other:
+            # the APR step over the ranks (conf/APR.ini): user tables sharded, item tables replicated, two
+            # all-reduces of item-gradient sums per step
+            from tfrec_amd.sharded import ShardedAprTrainer
+            apr = ShardedAprTrainer(dev, U, I, d, 0.05, 0.0, 1.0, 0.05, seed=2018, device=cuda)
+            for s in range(3):
+                apr.step(*batch(s), global_batch=B * world)
+            barrier()
+            t1 = time.perf_counter()
+            apr_steps = 10
+            for s in range(apr_steps):
+                apr.step(*batch(3 + s), global_batch=B * world)
+            barrier()
+            dt = time.perf_counter() - t1
+            if world > 1:
+                tm = torch.tensor([dt], device=cuda, dtype=torch.float64)
+                torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
+                dt = float(tm.item())
+            apr_bytes = 84 * d + 68
+            per_gpu = B * apr_bytes / (dt / apr_steps) / 1e9
+            out["other_paths"] = {"apr_adagrad_step": {
+                "triples_per_s": world * B * apr_steps / dt, "ms_per_step": dt * 1e3 / apr_steps, "batch_per_gpu": B,
+                "parallelism": "user tables row-sharded over %d GPUs, item tables replicated, two all-reduces per step" % world,
+                "roofline": {"bound": "hbm", "achieved": per_gpu, "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU", "frac": per_gpu / HBM_PEAK_GBS,
+                             "algorithmic_bytes_per_triple": apr_bytes}}}
+            del apr
         if rank == 0 and world == 1 and not args.force_sharded:
             # ---- roofline of the step's kernels: HIP events recorded by the library on its own stream
             # (un-pipelined steps, so that the index phase is timed on the same stream as the row passes)

@@ -201,6 +201,33 @@ int tfrec_apr_adagrad_step(tfrec_ctx *ctx, float *d_P, float *d_Q, float *d_b,
                            const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg, int64_t B,
                            float lr, float reg, float reg_adv, float eps, double *d_loss);
 
+/* The APR step of a GPU that holds a shard of P (with its accumulator and delta table) and full
+ * copies of Q, b, their accumulators and deltas.  Four calls and two all-reduces make one step:
+ *   1) tfrec_apr_dense_delta_grads   delta_P rows of this GPU's users (model/APR.py:116-132); d_G =
+ *      [I*d | I] zeroed and filled with the raw sums of d L_bpr / d(Q, b) over this GPU's triples
+ *      -> all-reduce d_G
+ *   2) tfrec_apr_delta_from_grads    delta_Q = eps * rows of G normalised one by one, delta_b = eps *
+ *      the bias part of G normalised as one vector (model/APR.py:124-132; rows without gradient
+ *      become zero, as the reference's full-table assignment makes them)
+ *   3) tfrec_apr_dense_adagrad_grads Adagrad step on this GPU's rows of P (model/APR.py:134-136) and
+ *      d_G = summed gradient of the optimised loss (model/APR.py:104-114) w.r.t. Q, b over this
+ *      GPU's triples -> all-reduce d_G.  B_total = triples of the whole step over all GPUs (the
+ *      mean-square term divides by B_total*d).  d_loss (optional): this GPU's share of the three
+ *      loss terms, to be summed over the GPUs.  Must directly follow call 1 for the same batch on
+ *      this context: it reuses that call's sorted index.
+ *   4) tfrec_adagrad_apply           acc += g*g; w -= lr*g/sqrt(acc) wherever g != 0, on the flat
+ *      [Q | b], [accQ | accb] buffers (the sparse Adagrad of the reference never visits entries
+ *      without gradient). */
+int tfrec_apr_dense_delta_grads(tfrec_ctx *ctx, const float *d_P, const float *d_Q, const float *d_b, float *d_dP, float *d_G,
+                                int64_t U, int64_t I, int d,
+                                const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg, int64_t B, float eps);
+int tfrec_apr_delta_from_grads(tfrec_ctx *ctx, const float *d_G, float *d_dQ, float *d_db, int64_t I, int d, float eps);
+int tfrec_apr_dense_adagrad_grads(tfrec_ctx *ctx, float *d_P, const float *d_Q, const float *d_b, float *d_accP,
+                                  const float *d_dP, const float *d_dQ, const float *d_db, float *d_G,
+                                  int64_t U, int64_t I, int d, int64_t B, int64_t B_total,
+                                  float lr, float reg, float reg_adv, double *d_loss);
+int tfrec_adagrad_apply(tfrec_ctx *ctx, float *d_w, float *d_acc, const float *d_g, float lr, int64_t n);
+
 /* DNS-BPR candidate selection, model/DNSBPR.py:74-79: for positive t with user d_users[t] and
  * candidates d_cand[t*C .. t*C+C), out_neg[t] = the candidate with the largest score
  * <P[u],Q[c]> + b[c]; the first maximum wins.  Only the C sampled rows are read (the reference

@@ -49,6 +49,89 @@ class CpuBackend:
         y_, x_ = _np(y), _np(x)
         y_[:] = (y_.astype(np.float64) + alpha * x_.astype(np.float64)).astype(np.float32)
 
+    # -- APR with a replicated item table: float64 restatement of model/APR.py:86-136 split where the
+    #    product splits it (delta gradients | normalisation | Adagrad gradients | dense Adagrad) --
+    @staticmethod
+    def _clipsig(r):
+        out = np.zeros_like(r)
+        m = (r >= -80.0) & (r <= 1e8)
+        out[m] = 1.0 / (1.0 + np.exp(r[m]))
+        return out
+
+    @staticmethod
+    def _clipsoftplus(r):
+        return np.logaddexp(0.0, -np.clip(r, -80.0, 1e8))
+
+    def apr_dense_delta_grads(self, P, Q, b, dP, G, users, pos, neg, eps):
+        P_, Q_, b_, dP_ = _np(P), _np(Q), _np(b), _np(dP)
+        I, d = Q_.shape
+        G.zero_()
+        self._apr_batch = (_np(users).astype(np.int64), _np(pos).astype(np.int64), _np(neg).astype(np.int64))
+        u, i, j = self._apr_batch
+        if len(u) == 0:
+            return
+        p, qi, qj = P_[u].astype(np.float64), Q_[i].astype(np.float64), Q_[j].astype(np.float64)
+        s = self._clipsig((p * (qi - qj)).sum(1) + (b_[i].astype(np.float64) - b_[j]))
+        gP = np.zeros(P_.shape); gQ = np.zeros(Q_.shape); gb = np.zeros(b_.shape)
+        np.add.at(gP, u, -s[:, None] * (qi - qj))
+        np.add.at(gQ, i, -s[:, None] * p); np.add.at(gQ, j, s[:, None] * p)
+        np.add.at(gb, i, -s); np.add.at(gb, j, s)
+        rows = np.unique(u)
+        n2 = (gP[rows] ** 2).sum(1, keepdims=True)
+        dP_[rows] = (eps * gP[rows] / np.sqrt(np.maximum(n2, 1e-12))).astype(np.float32)
+        G_ = _np(G)
+        G_[: I * d] = gQ.astype(np.float32).reshape(-1)
+        G_[I * d:] = gb.astype(np.float32)
+
+    def apr_delta_from_grads(self, G, dQ, db, eps):
+        I, d = dQ.shape
+        G_ = _np(G).astype(np.float64)
+        g, gb = G_[: I * d].reshape(I, d), G_[I * d:]
+        _np(dQ)[:] = (eps * g / np.sqrt(np.maximum((g ** 2).sum(1, keepdims=True), 1e-12))).astype(np.float32)
+        _np(db)[:] = (eps * gb / np.sqrt(max((gb ** 2).sum(), 1e-12))).astype(np.float32)
+
+    def apr_dense_adagrad_grads(self, P, Q, b, accP, dP, dQ, db, G, n_local, n_total, lr, reg, reg_adv, loss=None):
+        P_, Q_, b_, accP_ = _np(P), _np(Q), _np(b), _np(accP)
+        dP_, dQ_, db_ = _np(dP), _np(dQ), _np(db)
+        I, d = Q_.shape
+        G.zero_()
+        u, i, j = self._apr_batch
+        assert len(u) == n_local
+        if n_local == 0:
+            if loss is not None:
+                loss.zero_()
+            return
+        f = np.float64
+        p, qi, qj = P_[u].astype(f), Q_[i].astype(f), Q_[j].astype(f)
+        bi, bj = b_[i].astype(f), b_[j].astype(f)
+        pa, qia, qja = p + dP_[u], qi + dQ_[i], qj + dQ_[j]
+        r = (p * (qi - qj)).sum(1) + (bi - bj)
+        ra = (pa * (qia - qja)).sum(1) + ((bi + db_[i]) - (bj + db_[j]))
+        s, sa = self._clipsig(r), reg_adv * self._clipsig(ra)
+        creg = 4.0 * reg / (n_total * d)
+        gP = np.zeros(P_.shape); gQ = np.zeros(Q_.shape); gb = np.zeros(b_.shape)
+        np.add.at(gP, u, -s[:, None] * (qi - qj) - sa[:, None] * (qia - qja) + creg * p)
+        c = s[:, None] * p + sa[:, None] * pa
+        np.add.at(gQ, i, -c + creg * qi); np.add.at(gQ, j, c + creg * qj)
+        np.add.at(gb, i, -(s + sa) + creg * d * bi); np.add.at(gb, j, (s + sa) + creg * d * bj)
+        rows = np.unique(u)
+        an = accP_[rows].astype(f) + gP[rows] ** 2
+        accP_[rows] = an.astype(np.float32)
+        P_[rows] = (P_[rows].astype(f) - lr * gP[rows] / np.sqrt(an)).astype(np.float32)
+        G_ = _np(G)
+        G_[: I * d] = gQ.astype(np.float32).reshape(-1)
+        G_[I * d:] = gb.astype(np.float32)
+        if loss is not None:
+            m = (p ** 2 + qi ** 2 + qj ** 2).sum(1) + d * (bi ** 2 + bj ** 2)
+            _np(loss)[:] = [self._clipsoftplus(r).sum(), self._clipsoftplus(ra).sum(), m.sum() / (n_total * d)]
+
+    def adagrad_apply(self, w, acc, g, lr):
+        w_, a_, g_ = _np(w), _np(acc), _np(g).astype(np.float64)
+        m = g_ != 0
+        an = a_[m].astype(np.float64) + g_[m] ** 2
+        a_[m] = an.astype(np.float32)
+        w_[m] = (w_[m].astype(np.float64) - lr * g_[m] / np.sqrt(an)).astype(np.float32)
+
     def sample_negatives(self, indptr, indices, n_users, n_items, n_neg, seed, stream, first):
         u, p, n, _ = orc.sample_negatives(_np(indptr), _np(indices), n_users, n_items, n_neg, seed, stream, first)
         return torch.from_numpy(u), torch.from_numpy(p), torch.from_numpy(n)

@@ -167,3 +167,109 @@ def test_sharded_epoch_sampler_on_the_gpu(oracle, item_mode):
     for a, c in ((P1, P), (Q1, Q), (b1, b)):
         np.testing.assert_allclose(a, c, rtol=1e-4, atol=1e-6)
     dev.close()
+
+
+def _apr_problem(U, I, d, B, steps, seed):
+    rng = np.random.default_rng(seed)
+    P = rng.uniform(-0.3, 0.3, (U, d)).astype(np.float32)
+    Q = rng.uniform(-0.3, 0.3, (I, d)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, I).astype(np.float32)
+    items = (rng.zipf(1.3, (steps, B)) % I).astype(np.int32)         # hot items: long duplicate runs
+    batches = [(rng.integers(0, U, B).astype(np.int32), items[s], rng.integers(0, I, B).astype(np.int32)) for s in range(steps)]
+    return (P, Q, b), batches
+
+
+APR_HP = dict(lr=0.05, reg=0.01, reg_adv=1.0, eps=0.05)
+
+
+def test_single_rank_apr_matches_unsharded_step(oracle):
+    """The four-call replicated-item APR step on one rank against tfrec_apr_adagrad_step and the oracle."""
+    from tfrec_amd.sharded import ShardedAprTrainer, make_device
+    dev = make_device(0)
+    cuda = torch.device("cuda", 0)
+    U, I, d, B, steps = 3000, 2000, 64, 20000, 3
+    params, batches = _apr_problem(U, I, d, B, steps, 5)
+    tr = ShardedAprTrainer(dev, U, I, d, APR_HP["lr"], APR_HP["reg"], APR_HP["reg_adv"], APR_HP["eps"], params=params)
+    P, Q, b = (dev.array(x.copy()) for x in params)
+    accP, accQ, accb = (dev.full(x.shape, 0.1) for x in params)
+    dP, dQ, db = (dev.zeros(x.shape, np.float32) for x in params)
+    oP, oQ, ob = (x.copy() for x in params)
+    oaP, oaQ, oab = (np.full_like(x, 0.1) for x in params)
+    ows = oracle.Workspace(U, I, d)
+    loss = torch.zeros(3, dtype=torch.float64, device=cuda)
+    ref_loss = dev.zeros(3, np.float64)
+    for u, i, j in batches:
+        tu, ti, tj = (torch.from_numpy(x).to(cuda) for x in (u, i, j))
+        tr.step(tu, ti, tj, global_batch=B, loss=loss)
+        dev.apr_adagrad_step(P, Q, b, accP, accQ, accb, dP, dQ, db, dev.array(u, np.int32), dev.array(i, np.int32), dev.array(j, np.int32),
+                             APR_HP["lr"], APR_HP["reg"], APR_HP["reg_adv"], APR_HP["eps"], loss=ref_loss)
+        want = oracle.apr_step(oP, oQ, ob, oaP, oaQ, oab, u, i, j, APR_HP["lr"], APR_HP["reg"], APR_HP["reg_adv"], APR_HP["eps"], ws=ows)
+        dev.synchronize()
+        np.testing.assert_allclose(loss.cpu().numpy(), ref_loss.numpy(), rtol=1e-6)
+        np.testing.assert_allclose(loss.cpu().numpy(), np.array(want), rtol=1e-5)
+    for got, unsharded, orc in ((tr.P, P, oP), (tr.Q_full, Q, oQ), (tr.b_full, b, ob), (tr.accP, accP, oaP),
+                                (tr._accQb[: I * d].view(I, d), accQ, oaQ), (tr._accQb[I * d:], accb, oab)):
+        g = got.cpu().numpy()
+        np.testing.assert_allclose(g, unsharded.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(g, orc, rtol=1e-4, atol=1e-6)
+    # phase two refuses to run without the phase one of the same batch before it
+    with pytest.raises(Exception):
+        dev.apr_dense_adagrad_grads(tr.P, tr.Q_full, tr.b_full, tr.accP, tr.dP, tr.dQ, tr.db, tr._G, B, B, 0.05, 0.0, 1.0)
+    dev.close()
+
+
+def _two_rank_apr_worker(rank, world, port, out_dir):
+    import os
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from test_gpu_sharded import _apr_problem, APR_HP
+    from tfrec_amd.sharded import ShardedAprTrainer, make_device
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    dev = make_device(0)
+    cuda = torch.device("cuda", 0)
+    U, I, d, B, steps = 3000, 2000, 64, 20000, 3
+    params, batches = _apr_problem(U, I, d, B, steps, 5)
+    tr = ShardedAprTrainer(dev, U, I, d, APR_HP["lr"], APR_HP["reg"], APR_HP["reg_adv"], APR_HP["eps"], params=params)
+    lo, hi = tr.user_range
+    losses = []
+    for u, i, j in batches:
+        m = (u >= lo) & (u < hi)
+        loss = torch.zeros(3, dtype=torch.float64, device=cuda)
+        tr.step(*(torch.from_numpy(x[m]).to(cuda) for x in (u, i, j)), loss=loss)
+        losses.append(loss.cpu().numpy())
+    P, Q, b = tr.gather_full()
+    dev.synchronize()
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "apr2.npz"), P=P.cpu().numpy(), Q=Q.cpu().numpy(), b=b.cpu().numpy(), loss=np.array(losses))
+    dist.barrier()
+    dist.destroy_process_group()
+    dev.close()
+
+
+def test_two_ranks_apr_match_one_rank(tmp_path):
+    """World size 2 (both ranks on the one GPU, gloo between them): the APR steps equal the unsharded ones."""
+    import socket
+    import torch.multiprocessing as mp
+    from tfrec_amd.device import Device
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_two_rank_apr_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = np.load(str(tmp_path / "apr2.npz"))
+    dev = Device(0)
+    U, I, d, B, steps = 3000, 2000, 64, 20000, 3
+    params, batches = _apr_problem(U, I, d, B, steps, 5)
+    P, Q, b = (dev.array(x.copy()) for x in params)
+    accP, accQ, accb = (dev.full(x.shape, 0.1) for x in params)
+    dP, dQ, db = (dev.zeros(x.shape, np.float32) for x in params)
+    loss = dev.zeros(3, np.float64)
+    for n, (u, i, j) in enumerate(batches):
+        dev.apr_adagrad_step(P, Q, b, accP, accQ, accb, dP, dQ, db, dev.array(u, np.int32), dev.array(i, np.int32), dev.array(j, np.int32),
+                             APR_HP["lr"], APR_HP["reg"], APR_HP["reg_adv"], APR_HP["eps"], loss=loss)
+        np.testing.assert_allclose(r["loss"][n], loss.numpy(), rtol=1e-5)
+    np.testing.assert_allclose(r["P"], P.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(r["Q"], Q.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(r["b"], b.numpy(), rtol=1e-4, atol=1e-6)
+    dev.close()

@@ -57,6 +57,10 @@ SIGNATURES = {
     "tfrec_axpy": (_int, [_p, _p, _p, _f, _i64]),
     "tfrec_apr_adagrad_step": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _i64,
                                       _f, _f, _f, _f, _p]),
+    "tfrec_apr_dense_delta_grads": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _i64, _f]),
+    "tfrec_apr_delta_from_grads": (_int, [_p, _p, _p, _p, _i64, _int, _f]),
+    "tfrec_apr_dense_adagrad_grads": (_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _int, _i64, _i64, _f, _f, _f, _p]),
+    "tfrec_adagrad_apply": (_int, [_p, _p, _p, _p, _f, _i64]),
     "tfrec_dns_select": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _i64, _int, _p]),
     "tfrec_score_topk": (_int, [_p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _i64, _p, _p, _int, _int, _p, _p]),
     "tfrec_score_topk_shard": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _i64, _p, _p, _int, _int, _p, _p]),

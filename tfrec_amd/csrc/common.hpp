@@ -53,6 +53,7 @@ struct tfrec_batch_slot {
     hipEvent_t ready = nullptr;              // recorded on the auxiliary stream after preparation
     hipEvent_t released = nullptr;           // recorded on the main stream after the step that consumed the slot
     bool has_released = false;
+    int apr_pending = 0;                     // 1 between the two calls of a replicated-item APR step
 };
 
 struct tfrec_ctx {

@@ -244,6 +244,7 @@ __global__ __launch_bounds__(256) void iota_keys_kernel(const int32_t *__restric
 // ------------------------------------------------------------------------------------------
 struct AprParams {
     float *P, *Q, *b, *accP, *accQ, *accb, *dP, *dQ, *db;
+    float *gQ, *gb;       // gradient-only item passes: [I, d] and [I] tables that receive the per-item sums
     float *stage;         // [B, d] phase 2: c_t = s*p + sa*(p+dp)
     float *sbuf;          // [B]    phase 1: s ; phase 2: s + sa
     const uint2 *pair;    // [B]    (i, j), range-checked
@@ -305,8 +306,10 @@ struct AprUser1Pol {
     }
 };
 
-// phase 1, item side: delta_Q rows, raw bias gradient into db, and sum of its squares
-template <int LPR_, int NCH_, int VEC_, bool FULL_>
+// phase 1, item side: delta_Q rows, raw bias gradient into db, and sum of its squares.
+// GRAD = true leaves the raw gradient sums in gQ / gb instead (they are then summed over the GPUs
+// before they are normalised).
+template <int LPR_, int NCH_, int VEC_, bool FULL_, bool GRAD = false>
 struct AprItem1Pol {
     enum { LPR = LPR_, NCH = NCH_, VEC = VEC_, DEPTH = 8 };
     using RowT = Row<LPR_, NCH_, VEC_>;
@@ -334,12 +337,17 @@ struct AprItem1Pol {
     __device__ __forceinline__ void apply(uint32_t key, const Seg *, const Acc<RowT> &acc, int gl) const
     {
         const uint32_t it = key - a.U;
-        const float n2 = group_sum<LPR_>(acc.v.dot_partial(acc.v));
-        const float sc = a.eps * rsqrtf(fmaxf(n2, 1e-12f));
-        RowT out = RowT::zero();
-        out.fma(sc, acc.v);
-        out.store(a.dQ + (size_t)it * DM::d(a.d), gl, DM::nchunk(a.nchunk));
-        if (gl == 0) a.db[it] = acc.s0;     // scaled once the global norm is known
+        if constexpr (GRAD) {
+            acc.v.store(a.gQ + (size_t)it * DM::d(a.d), gl, DM::nchunk(a.nchunk));
+            if (gl == 0) a.gb[it] = acc.s0;
+        } else {
+            const float n2 = group_sum<LPR_>(acc.v.dot_partial(acc.v));
+            const float sc = a.eps * rsqrtf(fmaxf(n2, 1e-12f));
+            RowT out = RowT::zero();
+            out.fma(sc, acc.v);
+            out.store(a.dQ + (size_t)it * DM::d(a.d), gl, DM::nchunk(a.nchunk));
+            if (gl == 0) a.db[it] = acc.s0;     // scaled once the global norm is known
+        }
     }
 };
 
@@ -417,8 +425,9 @@ struct AprUser2Pol {
     }
 };
 
-// phase 2, item side
-template <int LPR_, int NCH_, int VEC_, bool FULL_>
+// phase 2, item side.  GRAD = true leaves the gradient sums (mean-square term included) in gQ / gb
+// and touches neither the tables nor the accumulators.
+template <int LPR_, int NCH_, int VEC_, bool FULL_, bool GRAD = false>
 struct AprItem2Pol {
     enum { LPR = LPR_, NCH = NCH_, VEC = VEC_, DEPTH = 8 };
     using RowT = Row<LPR_, NCH_, VEC_>;
@@ -454,6 +463,11 @@ struct AprItem2Pol {
         const float n = (float)acc.cnt, creg = a.reg_coef, lr = a.lr;
         // every occurrence adds creg*q (rows) and creg*d*b (bias) from the mean-square term
         const RowT g = acc.v.map2(q, [=](float gv, float qv) { return fmaf(n * creg, qv, gv); });
+        if constexpr (GRAD) {
+            g.store(a.gQ + (size_t)it * DM::d(a.d), gl, DM::nchunk(a.nchunk));
+            if (gl == 0) a.gb[it] = fmaf(n * creg * (float)DM::d(a.d), bk, acc.s0);
+            return;
+        }
         const RowT ac = RowT::load(arow, gl, DM::nchunk(a.nchunk));
         const RowT an = ac.map2(g, [](float av, float gv) { return fmaf(gv, gv, av); });
         an.store(arow, gl, DM::nchunk(a.nchunk));
@@ -618,7 +632,7 @@ static int slot_prepare(tfrec_ctx *ctx, tfrec_batch_slot &sl, hipStream_t stream
                                                                  vals_in, sl.pair, ctx->d_flags);
     TF_HIP(hipGetLastError());
     TF_TRY(tfrec_sort_pairs(sort_tmp, sort_bytes, keys_in, sl.keys, vals_in, sl.vals, (size_t)3 * n, total_bits, stream));
-    sl.B = B; sl.U = U; sl.I = I; sl.K = K; sl.next_k = 0;
+    sl.B = B; sl.U = U; sl.I = I; sl.K = K; sl.next_k = 0; sl.apr_pending = 0;
     sl.kmask = kb >= 32 ? 0xffffffffu : ((1u << kb) - 1u);
     return TFREC_OK;
 }
@@ -1016,6 +1030,188 @@ extern "C" int tfrec_apr_adagrad_step(tfrec_ctx *ctx, float *d_P, float *d_Q, fl
         }
         return TFREC_OK;
     });
+}
+
+// ------------------------------------------------------------------------------------------
+// APR with a replicated item table: each GPU holds a shard of P (+ accumulator, + delta) and full
+// copies of Q, b, their accumulators and deltas.  The user side of both phases is local; the item
+// side leaves gradient sums in a zeroed table G = [I*d rows | I biases] that the caller sums over
+// the GPUs; the normalisation (phase 1) and the Adagrad update (phase 2) then run densely on every
+// copy.  Rows no triple touches have a zero gradient: their delta is zero (model/APR.py:124-132
+// rewrites the whole delta tables every step) and the Adagrad update leaves them unchanged.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void apr_delta_rows_kernel(const float *__restrict__ g, float *__restrict__ dq, int64_t rows, int d,
+                                                             float eps)
+{
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int l = threadIdx.x & 63;
+    if (r >= rows) return;
+    const float *gr = g + (size_t)r * d;
+    float n2 = 0.f;
+    for (int f = l; f < d; f += 64) n2 = fmaf(gr[f], gr[f], n2);
+    for (int m = 32; m > 0; m >>= 1) n2 += __shfl_xor(n2, m);
+    const float sc = eps * rsqrtf(fmaxf(n2, 1e-12f));
+    for (int f = l; f < d; f += 64) dq[(size_t)r * d + f] = sc * gr[f];
+}
+
+__global__ __launch_bounds__(256) void sum_squares_kernel(const float *__restrict__ x, int64_t n, double *__restrict__ out)
+{
+    __shared__ double red[256];
+    double v = 0.0;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) v += (double)x[t] * (double)x[t];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void apr_bias_delta_kernel(const float *__restrict__ gb, float *__restrict__ db, int64_t n,
+                                                             const double *__restrict__ norm2, float eps)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) db[t] = gb[t] * (eps * rsqrtf(fmaxf((float)norm2[0], 1e-12f)));
+}
+
+// acc += g*g ; w -= lr*g/sqrt(acc) where g != 0 (sparse Adagrad never visits the other entries)
+__global__ __launch_bounds__(256) void adagrad_apply_kernel(float *__restrict__ w, float *__restrict__ acc, const float *__restrict__ g,
+                                                            float lr, int64_t n)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const float gv = g[t];
+    if (gv == 0.f) return;
+    const float an = fmaf(gv, gv, acc[t]);
+    acc[t] = an;
+    w[t] = w[t] - lr * gv / sqrtf(an);
+}
+
+static int apr_common(tfrec_ctx *ctx, AprParams *a, RowCfg *cfg, StepWs *w, const tfrec_batch_slot &sl, int64_t B, int d,
+                      std::initializer_list<const void *> tables)
+{
+    TF_REQUIRE(pick_cfg(d, all_aligned16(tables), cfg), TFREC_EUNSUP, "factor size d=%d is not supported (max 256)", d);
+    TF_TRY(step_ws_carve(ctx, B, d, *cfg, w));
+    a->stage = w->stage; a->sbuf = w->sbuf; a->pair = sl.pair;
+    a->d = d; a->nchunk = d / cfg->vec;
+    return TFREC_OK;
+}
+
+extern "C" int tfrec_apr_dense_delta_grads(tfrec_ctx *ctx, const float *d_P, const float *d_Q, const float *d_b, float *d_dP,
+                                           float *d_G, int64_t U, int64_t I, int d, const int32_t *d_users, const int32_t *d_pos,
+                                           const int32_t *d_neg, int64_t B, float eps)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_TRY(check_step_args(d_P, d_Q, d_b, U, I, d, d_users, d_pos, d_neg, B));
+    TF_REQUIRE(d_dP != nullptr, TFREC_EINVAL, "null delta table");
+    TF_REQUIRE(d_G != nullptr && ((uintptr_t)d_G & 15u) == 0, TFREC_EINVAL, "gradient table missing or not 16-byte aligned");
+    TF_HIP(hipMemsetAsync(d_G, 0, sizeof(float) * ((size_t)I * d + (size_t)I), ctx->stream));
+    tfrec_batch_slot &sl = ctx->slots[2];
+    sl.apr_pending = 0;
+    if (B == 0) { sl.B = 0; sl.U = U; sl.I = I; sl.apr_pending = 1; return TFREC_OK; }
+    tfrec_marks_reset(ctx);
+    tfrec_mark(ctx, "start");
+    TF_TRY(slot_prepare(ctx, sl, ctx->stream, d_users, d_pos, d_neg, B, U, I));
+    tfrec_mark(ctx, "index");
+    AprParams a{};
+    RowCfg cfg;
+    StepWs w;
+    TF_TRY(apr_common(ctx, &a, &cfg, &w, sl, B, d, {d_P, d_Q, d_dP}));
+    a.P = const_cast<float *>(d_P); a.Q = const_cast<float *>(d_Q); a.b = const_cast<float *>(d_b);
+    a.dP = d_dP; a.gQ = d_G; a.gb = d_G + (size_t)I * d;
+    a.users = d_users; a.U = (uint32_t)U; a.eps = eps;
+    TF_TRY(dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC, bool FULL>() -> int {
+        TF_TRY(run_pass(ctx, AprUser1Pol<LPR, NCH, VEC, FULL>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, false,
+                        "delta_user_tile", "delta_user_fixup"));
+        return run_pass(ctx, AprItem1Pol<LPR, NCH, VEC, FULL, true>{a}, w, sl.keys, sl.vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false,
+                        "delta_item_tile", "delta_item_fixup");
+    }));
+    sl.apr_pending = 1;
+    return TFREC_OK;
+}
+
+extern "C" int tfrec_apr_delta_from_grads(tfrec_ctx *ctx, const float *d_G, float *d_dQ, float *d_db, int64_t I, int d, float eps)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_REQUIRE(d_G && d_dQ && d_db && I > 0 && I < (1ll << 31) && d > 0, TFREC_EINVAL, "bad gradient or delta table");
+    TF_TRY(tfrec_ws_require(ctx, ctx->ws_used + 8192));
+    double *part = (double *)tfrec_ws_take(ctx, sizeof(double) * 520);
+    TF_REQUIRE(part != nullptr, TFREC_ENOMEM, "internal: workspace carve failed");
+    apr_delta_rows_kernel<<<(unsigned)((I + 3) / 4), 256, 0, ctx->stream>>>(d_G, d_dQ, I, d, eps);
+    TF_HIP(hipGetLastError());
+    const int nb = (int)((I + 255) / 256 < 512 ? (I + 255) / 256 : 512);
+    sum_squares_kernel<<<nb, 256, 0, ctx->stream>>>(d_G + (size_t)I * d, I, part);
+    TF_HIP(hipGetLastError());
+    loss_finalize_kernel<1><<<1, 256, 0, ctx->stream>>>(part, nb, part + 512);
+    TF_HIP(hipGetLastError());
+    apr_bias_delta_kernel<<<(unsigned)((I + 255) / 256), 256, 0, ctx->stream>>>(d_G + (size_t)I * d, d_db, I, part + 512, eps);
+    TF_HIP(hipGetLastError());
+    return TFREC_OK;
+}
+
+extern "C" int tfrec_apr_dense_adagrad_grads(tfrec_ctx *ctx, float *d_P, const float *d_Q, const float *d_b, float *d_accP,
+                                             const float *d_dP, const float *d_dQ, const float *d_db, float *d_G, int64_t U,
+                                             int64_t I, int d, int64_t B, int64_t B_total, float lr, float reg, float reg_adv,
+                                             double *d_loss)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_TRY(check_step_args(d_P, d_Q, d_b, U, I, d, d_P, d_P, d_P, B));
+    TF_REQUIRE(d_accP && d_dP && d_dQ && d_db, TFREC_EINVAL, "null accumulator or delta table");
+    TF_REQUIRE(d_G != nullptr && ((uintptr_t)d_G & 15u) == 0, TFREC_EINVAL, "gradient table missing or not 16-byte aligned");
+    TF_REQUIRE(B_total >= B && B_total >= 1, TFREC_EINVAL, "the batch size over all GPUs is below this GPU's share");
+    tfrec_batch_slot &sl = ctx->slots[2];
+    TF_REQUIRE(sl.apr_pending == 1 && sl.B == B && sl.U == U && sl.I == I, TFREC_EINVAL,
+               "tfrec_apr_dense_delta_grads of the same batch must be the previous step call on this context");
+    sl.apr_pending = 0;
+    TF_HIP(hipMemsetAsync(d_G, 0, sizeof(float) * ((size_t)I * d + (size_t)I), ctx->stream));
+    if (B == 0) {
+        sl.B = -1;
+        if (d_loss) TF_HIP(hipMemsetAsync(d_loss, 0, 3 * sizeof(double), ctx->stream));
+        return TFREC_OK;
+    }
+    tfrec_marks_reset(ctx);
+    tfrec_mark(ctx, "start");
+    AprParams a{};
+    RowCfg cfg;
+    StepWs w;
+    TF_TRY(apr_common(ctx, &a, &cfg, &w, sl, B, d, {d_P, d_Q, d_accP, d_dP, d_dQ}));
+    a.P = d_P; a.Q = const_cast<float *>(d_Q); a.b = const_cast<float *>(d_b); a.accP = d_accP;
+    a.dP = const_cast<float *>(d_dP); a.dQ = const_cast<float *>(d_dQ); a.db = const_cast<float *>(d_db);
+    a.gQ = d_G; a.gb = d_G + (size_t)I * d;
+    a.U = (uint32_t)U; a.lr = lr; a.reg_adv = reg_adv;
+    a.reg_coef = (float)(4.0 * (double)reg / ((double)B_total * (double)d));
+    const bool want_loss = d_loss != nullptr;
+    return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC, bool FULL>() -> int {
+        if (want_loss) {
+            TF_TRY(run_pass(ctx, AprUser2Pol<LPR, NCH, VEC, FULL, true>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, true,
+                            "user_tile", "user_fixup"));
+            loss_finalize_kernel<3><<<1, 256, 0, ctx->stream>>>(w.loss_part, w.blocks_u, w.scalars + 4);
+            TF_HIP(hipGetLastError());
+        } else {
+            TF_TRY(run_pass(ctx, AprUser2Pol<LPR, NCH, VEC, FULL, false>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, false,
+                            "user_tile", "user_fixup"));
+        }
+        TF_TRY(run_pass(ctx, AprItem2Pol<LPR, NCH, VEC, FULL, true>{a}, w, sl.keys, sl.vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false,
+                        "item_tile", "item_fixup"));
+        if (want_loss) {
+            // this GPU's share of the three sums; the third is divided by the entry count of the whole batch
+            apr_loss_out_kernel<<<1, 1, 0, ctx->stream>>>(w.scalars + 4, d_loss, 1.0 / ((double)B_total * (double)d));
+            TF_HIP(hipGetLastError());
+        }
+        return TFREC_OK;
+    });
+}
+
+extern "C" int tfrec_adagrad_apply(tfrec_ctx *ctx, float *d_w, float *d_acc, const float *d_g, float lr, int64_t n)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_REQUIRE(n >= 0, TFREC_EINVAL, "negative length");
+    if (n == 0) return TFREC_OK;
+    TF_REQUIRE(d_w && d_acc && d_g, TFREC_EINVAL, "null array");
+    adagrad_apply_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(d_w, d_acc, d_g, lr, n);
+    TF_HIP(hipGetLastError());
+    return TFREC_OK;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -276,6 +276,30 @@ class Device:
                                                    _ptr(dP), _ptr(dQ), _ptr(db), U, I, d, _ptr(users), _ptr(pos), _ptr(neg), B,
                                                    float(lr), float(reg), float(reg_adv), float(eps), _ptr(loss)))
 
+    # -- APR with a replicated item table (see include/tfrec_amd.h for the four-call protocol) --
+    def apr_dense_delta_grads(self, P, Q, b, dP, G, users, pos, neg, eps):
+        U, d = _shape(P)
+        I = _shape(Q)[0]
+        B = _shape(users)[0]
+        _lib.check(self.lib.tfrec_apr_dense_delta_grads(self.h, _ptr(P), _ptr(Q), _ptr(b), _ptr(dP), _ptr(G), U, I, d,
+                                                        _ptr(users), _ptr(pos), _ptr(neg), B, float(eps)))
+
+    def apr_delta_from_grads(self, G, dQ, db, eps):
+        I, d = _shape(dQ)
+        _lib.check(self.lib.tfrec_apr_delta_from_grads(self.h, _ptr(G), _ptr(dQ), _ptr(db), I, d, float(eps)))
+
+    def apr_dense_adagrad_grads(self, P, Q, b, accP, dP, dQ, db, G, n_local, n_total, lr, reg, reg_adv, loss=None):
+        U, d = _shape(P)
+        I = _shape(Q)[0]
+        _lib.check(self.lib.tfrec_apr_dense_adagrad_grads(self.h, _ptr(P), _ptr(Q), _ptr(b), _ptr(accP), _ptr(dP), _ptr(dQ), _ptr(db),
+                                                          _ptr(G), U, I, d, int(n_local), int(n_total), float(lr), float(reg),
+                                                          float(reg_adv), _ptr(loss)))
+
+    def adagrad_apply(self, w, acc, g, lr, n=None):
+        """acc += g*g; w -= lr*g/sqrt(acc) wherever g != 0."""
+        n = int(n) if n is not None else int(np.prod(_shape(w)))
+        _lib.check(self.lib.tfrec_adagrad_apply(self.h, _ptr(w), _ptr(acc), _ptr(g), float(lr), n))
+
     def dns_select(self, P, Q, b, users, cand, out=None):
         """cand: int32 [n_pos, C] -> best-scored candidate per positive (model/DNSBPR.py:74-79)."""
         U, d = _shape(P)

@@ -19,6 +19,8 @@ Layout
     of the shape of [Q | b]; one all-reduce sums the tables; every rank applies the same update to
     its copy.  No host synchronisation, one collective per step.  For evaluation each rank scores
     its own item range of the copy, as in the sharded layout.
+  * APR (``ShardedAprTrainer``): the replicated-item layout with two all-reduces per step, one of the
+    perturbation gradients and one of the Adagrad gradients.
   * evaluation with the replicated item table: user-sharded -- every rank evaluates the users it owns
     against all items, only the metric sums are all-reduced.
   * evaluation: item-sharded.  The factor rows of a chunk of evaluated users are broadcast from
@@ -71,6 +73,18 @@ class HipBackend:
 
     def axpy(self, y, x, alpha):
         self.dev.axpy(y, x, alpha)
+
+    def apr_dense_delta_grads(self, P, Q, b, dP, G, users, pos, neg, eps):
+        self.dev.apr_dense_delta_grads(P, Q, b, dP, G, users, pos, neg, eps)
+
+    def apr_delta_from_grads(self, G, dQ, db, eps):
+        self.dev.apr_delta_from_grads(G, dQ, db, eps)
+
+    def apr_dense_adagrad_grads(self, P, Q, b, accP, dP, dQ, db, G, n_local, n_total, lr, reg, reg_adv, loss=None):
+        self.dev.apr_dense_adagrad_grads(P, Q, b, accP, dP, dQ, db, G, n_local, n_total, lr, reg, reg_adv, loss=loss)
+
+    def adagrad_apply(self, w, acc, g, lr):
+        self.dev.adagrad_apply(w, acc, g, lr)
 
     def sample_negatives(self, indptr, indices, n_users, n_items, n_neg, seed, stream, first):
         nnz = indices.shape[0]
@@ -300,6 +314,104 @@ class ShardedBprTrainer:
         if self.item_mode == "dense":
             return cat(self.P, self.U), self.Q_full.clone(), self.b_full.clone()
         return cat(self.P, self.U), cat(self.Q, self.I), cat(self.b, self.I)
+
+
+class ShardedAprTrainer:
+    """APR (model/APR.py:86-136, 156-164) over several GPUs: P, its Adagrad accumulator and its delta
+    table are sharded by user range; Q, b with their accumulators and deltas are replicated (the
+    layout ``ShardedBprTrainer`` calls "dense").  Every triple goes to the rank that owns its user.
+    One step is four library calls and two all-reduces of a table of the shape of [Q | b]:
+
+      delta gradients of the local triples -> all-reduce -> delta_Q, delta_b on every copy
+      Adagrad gradients of the local triples (P updated locally) -> all-reduce -> Adagrad on every copy
+
+    The adversarial perturbation normalises the item gradients of the WHOLE step (rows one by one,
+    the bias gradient as one vector), which is why the sums have to be complete before phase two."""
+
+    item_mode = "dense"
+
+    def __init__(self, dev_or_backend, U, I, d, lr, reg, reg_adv, eps, params=None, seed=2018, device=None, group=None,
+                 initial_accumulator=0.1):
+        self.backend = dev_or_backend if hasattr(dev_or_backend, "uniform_rows") else HipBackend(dev_or_backend)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.U, self.I, self.d = int(U), int(I), int(d)
+        self.lr, self.reg, self.reg_adv, self.eps = float(lr), float(reg), float(reg_adv), float(eps)
+        self.upr, self.ipr = _part(self.U, self.world), _part(self.I, self.world)
+        self.user_range = (min(self.rank * self.upr, self.U), min((self.rank + 1) * self.upr, self.U))
+        self.item_range = (min(self.rank * self.ipr, self.I), min((self.rank + 1) * self.ipr, self.I))
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        self.device = device
+        lo, hi = self.user_range
+        n_item = self.I * (self.d + 1)
+        self._Qb = torch.zeros(n_item, dtype=torch.float32, device=device)
+        self.Q_full = self._Qb[: self.I * self.d].view(self.I, self.d)
+        self.b_full = self._Qb[self.I * self.d:]
+        if params is not None:
+            # pretrained [P, Q, b] (model/APR.py:47-53): every rank takes its rows
+            P0, Q0, b0 = (np.ascontiguousarray(x, dtype=np.float32) for x in params)
+            assert P0.shape == (self.U, self.d) and Q0.shape == (self.I, self.d) and b0.shape == (self.I,)
+            self.P = torch.from_numpy(P0[lo:hi].copy()).to(device)
+            self.Q_full.copy_(torch.from_numpy(Q0))
+            self.b_full.copy_(torch.from_numpy(b0))
+        else:
+            self.P = self.backend.uniform_rows(lo, hi, self.d, -0.05, 0.05, seed * 2 + 1, device)
+            self.Q_full.copy_(self.backend.uniform_rows(0, self.I, self.d, -0.05, 0.05, seed * 2 + 2, device))
+        self.accP = torch.full_like(self.P, float(initial_accumulator))
+        self.dP = torch.zeros_like(self.P)
+        self._accQb = torch.full_like(self._Qb, float(initial_accumulator))
+        self._dQb = torch.zeros_like(self._Qb)
+        self.dQ = self._dQb[: self.I * self.d].view(self.I, self.d)
+        self.db = self._dQb[self.I * self.d:]
+        self._G = torch.zeros_like(self._Qb)
+        self.Q = self.Q_full[self.item_range[0]:self.item_range[1]]
+        self.b = self.b_full[self.item_range[0]:self.item_range[1]]
+
+    def _sum_over_ranks(self, t):
+        if self.world > 1:
+            _drain_for_gloo(t, self.group)
+            dist.all_reduce(t, group=self.group)
+
+    def step(self, users, pos, neg, global_batch=None, loss=None):
+        """One global minibatch step; collective (an empty local batch is allowed).  ``global_batch``:
+        triples of the step over all ranks (it scales the mean-square term); counted with one more
+        all-reduce and a host read when not given.  ``loss``: optional float64[3] device tensor that
+        receives the step's three loss terms summed over the ranks."""
+        be = self.backend
+        users = (users.to(torch.int32) - self.user_range[0]).contiguous()
+        pos, neg = pos.to(torch.int32).contiguous(), neg.to(torch.int32).contiguous()
+        n_local = int(users.shape[0])
+        if global_batch is None:
+            cnt = torch.tensor([n_local], dtype=torch.int64, device=self.device)
+            self._sum_over_ranks(cnt)
+            global_batch = int(cnt.item())
+        if global_batch == 0:
+            return
+        be.apr_dense_delta_grads(self.P, self.Q_full, self.b_full, self.dP, self._G, users, pos, neg, self.eps)
+        self._sum_over_ranks(self._G)
+        be.apr_delta_from_grads(self._G, self.dQ, self.db, self.eps)
+        be.apr_dense_adagrad_grads(self.P, self.Q_full, self.b_full, self.accP, self.dP, self.dQ, self.db, self._G, n_local,
+                                   global_batch, self.lr, self.reg, self.reg_adv, loss=loss)
+        self._sum_over_ranks(self._G)
+        be.adagrad_apply(self._Qb, self._accQb, self._G, self.lr)
+        if loss is not None:
+            self._sum_over_ranks(loss)
+
+    def full_item_table(self):
+        return self.Q_full, self.b_full
+
+    def gather_full(self):
+        """(P, Q, b) assembled on every rank (testing / checkpointing)."""
+        if self.world == 1:
+            return self.P.clone(), self.Q_full.clone(), self.b_full.clone()
+        pad = torch.zeros((self.upr, self.d), dtype=self.P.dtype, device=self.device)
+        pad[: self.P.shape[0]] = self.P
+        outs = [torch.empty_like(pad) for _ in range(self.world)]
+        _drain_for_gloo(pad, self.group)
+        dist.all_gather(outs, pad, group=self.group)
+        return torch.cat(outs)[: self.U], self.Q_full.clone(), self.b_full.clone()
 
 
 class ShardedEvaluator:
