@@ -185,3 +185,24 @@ def test_run_model_end_to_end(tmp_path, extra):
     logs = os.listdir(tmp_path / "log" / "ml100k" / "BPR")
     assert len(logs) == 1 and logs[0].startswith("BPR_log_lr=0.01_reg=0.05_factors_num=20_batch_size=512_epochs=1_")
     assert ("sampler=device" in logs[0]) == bool(extra)
+
+
+def test_pop_goes_through_the_dense_evaluator(dev, oracle, golden_ml100k):
+    """Pop has no factors: FoldOutEvaluator takes its _predict() matrix through eval_rating_matrix on the
+    GPU (model/Pop.py:21-24, evaluator/evaluator.py:29-32).  Item counts tie often; ties rank by ascending
+    item id here and in the oracle (the reference's order among equal scores is unspecified)."""
+    from tfrec_amd.evaluator import FoldOutEvaluator
+    from tfrec_amd.model import Pop
+    ds = ml100k(golden_ml100k)
+    ev = FoldOutEvaluator(ds.train_matrix, ds.test_matrix, top_k=50)
+    Pop.logger = _Log()
+    model = Pop(None, {}, ds, ev)
+    model.train_model()
+    counts = np.asarray((ds.train_matrix != 0).sum(axis=0)).ravel().astype(np.float32)
+    assert np.array_equal(model.ranking_score, counts)
+    R = model._predict()
+    assert R.shape == ds.train_matrix.shape and R.flags["C_CONTIGUOUS"] and R.dtype == np.float32
+    got = np.array([float(x) for x in Pop.logger.lines[-1].split("result:\t")[1].split("\t")], np.float32)
+    want, _ = oracle.eval_dense(R, oracle.csr_to_user_dict(ds.train_matrix), oracle.csr_to_user_dict(ds.test_matrix), 50)
+    np.testing.assert_allclose(got, np.asarray(want).reshape(-1), rtol=1e-5, atol=1e-7)
+    assert got[0] > 0.05          # popularity is a real baseline on ML-100k

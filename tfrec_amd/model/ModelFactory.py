@@ -15,6 +15,7 @@ from ..utils import Logger
 from .APR import APR
 from .BPR import BPR
 from .DNSBPR import DNSBPR
+from .Pop import Pop
 
 _BIN = {ast.Add: operator.add, ast.Sub: operator.sub, ast.Mult: operator.mul, ast.Div: operator.truediv,
         ast.FloorDiv: operator.floordiv, ast.Pow: operator.pow, ast.Mod: operator.mod}
@@ -47,7 +48,7 @@ def parse_value(text):
 class ModelFactory(object):
     def __init__(self, root="."):
         self.root = root
-        self.model_dict = {"BPR": BPR, "DNSBPR": DNSBPR, "APR": APR}
+        self.model_dict = {"BPR": BPR, "DNSBPR": DNSBPR, "APR": APR, "Pop": Pop}
 
     def get_model(self):
         tfrec_config, model_config = self._read_config()
