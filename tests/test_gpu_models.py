@@ -206,3 +206,49 @@ def test_pop_goes_through_the_dense_evaluator(dev, oracle, golden_ml100k):
     want, _ = oracle.eval_dense(R, oracle.csr_to_user_dict(ds.train_matrix), oracle.csr_to_user_dict(ds.test_matrix), 50)
     np.testing.assert_allclose(got, np.asarray(want).reshape(-1), rtol=1e-5, atol=1e-7)
     assert got[0] > 0.05          # popularity is a real baseline on ML-100k
+
+
+@pytest.mark.parametrize("sampler", ["host", "device"])
+def test_resume_from_a_checkpoint_continues_the_same_run(dev, tmp_path, sampler):
+    """Two epochs in one go against one epoch, a fresh process-like restart from the checkpoint, and the
+    second epoch: the same parameters bit for bit (host sampler: numpy's generator state travels in the
+    checkpoint; device sampler: draws are a function of seed, epoch and position)."""
+    from tfrec_amd.evaluator import FoldOutEvaluator
+    from tfrec_amd.model import APR, BPR
+    ds = synthetic(21)
+    ev = FoldOutEvaluator(ds.train_matrix, ds.test_matrix, top_k=10)
+    base = {"factors_num": 16, "lr": 0.05, "reg": 0.01, "epochs": 2, "batch_size": 64, "sampler": sampler}
+    BPR.logger = _Log()
+    np.random.seed(5)
+    whole = BPR(dev, dict(base), ds, ev)
+    whole.train_model()
+    ck = str(tmp_path / ("bpr_%s.npz" % sampler))
+    np.random.seed(5)
+    first = BPR(dev, dict(base, epochs=1, checkpoint_file=ck), ds, ev)
+    first.train_model()
+    np.random.seed(12345)                                  # a restart does not inherit the generator
+    second = BPR(dev, dict(base, checkpoint_file=ck, resume=True), ds, ev)
+    second.train_model()
+    assert any("resumed from" in l for l in BPR.logger.lines)
+    for a, c in zip(second.mf.parameters(), whole.mf.parameters()):
+        assert np.array_equal(a, c)
+    if sampler == "host":
+        # APR: the Adagrad accumulators travel too
+        P, Q, b = whole.mf.parameters()
+        pre = str(tmp_path / "pre.npz")
+        np.savez(pre, P=P, Q=Q, b=b)
+        acfg = {"factors_num": 16, "lr": 0.05, "reg": 0.0, "reg_adv": 1.0, "eps": 0.05, "epochs": 2, "batch_size": 64, "pretrain_file": pre}
+        APR.logger = _Log()
+        np.random.seed(6)
+        awhole = APR(dev, dict(acfg), ds, ev)
+        awhole.train_model()
+        ack = str(tmp_path / "apr.npz")
+        np.random.seed(6)
+        APR(dev, dict(acfg, epochs=1, checkpoint_file=ack), ds, ev).train_model()
+        np.random.seed(777)
+        asecond = APR(dev, dict(acfg, checkpoint_file=ack, resume=True), ds, ev)
+        asecond.train_model()
+        for a, c in zip(asecond.mf.parameters(), awhole.mf.parameters()):
+            assert np.array_equal(a, c)
+        for a, c in zip(asecond.accumulators, awhole.accumulators):
+            assert np.array_equal(a.numpy(), c.numpy())

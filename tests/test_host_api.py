@@ -104,3 +104,27 @@ def test_param_files(tmp_path):
         pickle.dump([os.path.join, 1], f)
     with pytest.raises(ValueError):
         read_param_pickle_safely(bad)
+
+
+def test_checkpoint_round_trip(tmp_path):
+    """Arrays, epoch number and numpy's legacy generator state survive save_checkpoint/load_checkpoint;
+    the file holds plain arrays only (it loads with allow_pickle=False)."""
+    from tfrec_amd.utils import load_checkpoint, save_checkpoint
+    rng = np.random.default_rng(0)
+    arrays = {"P": rng.normal(size=(5, 3)).astype(np.float32), "b": rng.normal(size=7).astype(np.float32)}
+    np.random.seed(99)
+    np.random.random_sample(11)
+    np.random.standard_normal(3)          # leaves a cached gaussian in the state
+    state = np.random.get_state()
+    want = np.random.random_sample(5)
+    path = str(tmp_path / "ck.npz")
+    save_checkpoint(path, arrays, 4, rng_state=state)
+    got, epoch, st = load_checkpoint(path)
+    assert epoch == 4 and set(got) == {"P", "b"}
+    assert all(np.array_equal(got[k], arrays[k]) for k in arrays)
+    np.random.set_state(st)
+    assert np.array_equal(np.random.random_sample(5), want)
+    save_checkpoint(path, arrays, 5)       # overwrite; no generator state (device sampler)
+    _, epoch, st = load_checkpoint(path)
+    assert epoch == 5 and st is None
+    assert not [f for f in os.listdir(tmp_path) if "tmp" in f]

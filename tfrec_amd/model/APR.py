@@ -12,6 +12,7 @@ from .base import AbstractRecommender, MatrixFactorization
 class APR(AbstractRecommender):
     def __init__(self, sess, config, dataset, evaluator):
         super(APR, self).__init__(sess, config, dataset, evaluator)
+        self.config = config
         train_matrix = dataset.train_matrix
         self.users_num, self.items_num = train_matrix.shape
         self.factors_num = config["factors_num"]
@@ -69,10 +70,17 @@ class APR(AbstractRecommender):
         self.logger.info(self.evaluator.metrics_info())
         result = self.evaluate_model()
         self.logger.info("pretrain:\t%s" % result)
-        for epoch in range(self.epochs):
+        for epoch in range(self._restore_checkpoint(self.config), self.epochs):
             self.train_model_epoch()
             result = self.evaluate_model()
             self.logger.info("%d:\t%s" % (epoch, result))
+            self._save_checkpoint(self.config, epoch)
+
+    def _checkpoint_arrays(self):
+        """Parameters and Adagrad accumulators; the delta tables are rebuilt by every step."""
+        out = dict(zip(("P", "Q", "b"), self.mf.device_parameters()))
+        out.update(zip(("accP", "accQ", "accb"), self.accumulators))
+        return out
 
     def device_factors(self):
         return (self.sess,) + tuple(self.mf.device_parameters())

@@ -10,6 +10,7 @@ from .base import AbstractRecommender, MatrixFactorization
 class BPR(AbstractRecommender):
     def __init__(self, sess, config, dataset, evaluator):
         super(BPR, self).__init__(sess, config, dataset, evaluator)
+        self.config = config
         train_matrix = dataset.train_matrix
         self.users_num, self.items_num = train_matrix.shape
         self.factors_num = config["factors_num"]
@@ -70,13 +71,20 @@ class BPR(AbstractRecommender):
 
     def train_model(self):
         self.logger.info(self.evaluator.metrics_info())
-        for epoch in range(self.epochs):
+        for epoch in range(self._restore_checkpoint(self.config), self.epochs):
             if self._device_sampler is not None:
                 self._train_epoch_on_device(epoch)
             else:
                 self._train_epoch(self.get_training_data())
             result = self.evaluate_model()
             self.logger.info("epoch %d:\t%s" % (epoch, result))
+            self._save_checkpoint(self.config, epoch)
+
+    def _checkpoint_arrays(self):
+        return dict(zip(("P", "Q", "b"), self.mf.device_parameters()))
+
+    def _uses_host_rng(self):
+        return self._device_sampler is None
 
     def device_factors(self):
         return (self.sess,) + tuple(self.mf.device_parameters())

@@ -75,3 +75,35 @@ def load_params(path, trusted=False):
         with open(path, "rb") as fin:
             return [np.asarray(x, dtype=np.float32) for x in pickle.load(fin)]
     return read_param_pickle_safely(path)
+
+
+def save_checkpoint(path, arrays, epoch, rng_state=None):
+    """Training state after ``epoch`` finished: named float32 arrays (P, Q, b and, for Adagrad models,
+    their accumulators), the epoch number and, for the host sampler, numpy's legacy generator state
+    (the device sampler needs none: its draws are a function of (seed, epoch, position)).  One .npz
+    of plain arrays, written next to the target and renamed so that an interrupted write leaves the
+    previous checkpoint intact."""
+    import os
+    out = {"arr_" + k: np.ascontiguousarray(v, dtype=np.float32) for k, v in arrays.items()}
+    out["epoch"] = np.int64(epoch)
+    if rng_state is not None:
+        name, keys, pos, has_gauss, cached = rng_state
+        if name != "MT19937":
+            raise ValueError("only the legacy MT19937 state is stored")
+        out["rng_keys"] = np.asarray(keys, dtype=np.uint32)
+        out["rng_rest"] = np.array([pos, has_gauss], dtype=np.int64)
+        out["rng_cached"] = np.float64(cached)
+    tmp = path + ".tmp.npz"
+    np.savez(tmp, **out)
+    os.replace(tmp, path)
+
+
+def load_checkpoint(path):
+    """(arrays dict, epoch, rng_state or None) as written by ``save_checkpoint``."""
+    z = np.load(path, allow_pickle=False)
+    arrays = {k[4:]: z[k] for k in z.files if k.startswith("arr_")}
+    rng = None
+    if "rng_keys" in z.files:
+        rest = z["rng_rest"]
+        rng = ("MT19937", z["rng_keys"], int(rest[0]), int(rest[1]), float(z["rng_cached"]))
+    return arrays, int(z["epoch"]), rng
