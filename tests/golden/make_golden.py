@@ -15,6 +15,8 @@ What produces what
 * sampler vectors        -> the reference's ``utils.random_choice``
   (utils/tools.py:39-49), ``utils.csr_to_user_dict`` (utils/tools.py:52-62) and
   ``data.DataIterator`` (data/dataiterator.py:158-192), imported from the tree.
+* splitter vectors       -> the reference's ``data/utils.py`` functions (data/utils.py:7-98), imported
+  from the tree (``--only-splitter`` regenerates just these).
 * training-step vectors  -> NOT the reference (TensorFlow is not installed):
   an independent float64 torch-autograd implementation of the graphs in
   model/BPR.py:36-48 and model/APR.py:64-136.  Parity with TensorFlow itself
@@ -349,13 +351,54 @@ def gen_train_steps():
     print("train-step cases:", len(save))
 
 
+def gen_splitter():
+    """Splitter vectors -> the reference's own data/utils.py functions (load_data, filter_data, remap_id,
+    split_by_ratio, split_by_loo: data/utils.py:7-98) on a small synthetic UIRT file with sparse raw ids,
+    rare items, short users and repeated timestamps; the random splits seeded through numpy's legacy generator."""
+    from data.utils import filter_data, load_data, remap_id, split_by_loo, split_by_ratio
+    rng = np.random.default_rng(31)
+    lines = []
+    for u in range(40):
+        n = int(rng.integers(1, 15))
+        for it in rng.choice(60, n, replace=False):
+            lines.append((100 + 3 * u, 1000 + 7 * int(it), int(rng.integers(1, 6)), 900000 + int(rng.integers(0, 12))))
+    raw = np.array([lines[i] for i in rng.permutation(len(lines))], dtype=np.int64)
+    work = os.path.join(ROOT, "build")            # scratch, not tracked
+    os.makedirs(work, exist_ok=True)
+    path = os.path.join(work, "splitter_input.txt")
+    np.savetxt(path, raw, fmt="%d", delimiter=",")
+    save = {"raw": raw}
+    cols = ["user", "item", "rating", "time"]
+    table = lambda a: np.stack([a[c] for c in cols], axis=1).astype(np.int64) if len(a) else np.zeros((0, 4), np.int64)
+    for name, (umin, imin) in {"nofilter": (0, 0), "filtered": (3, 2)}.items():
+        data = remap_id(filter_data(load_data(path, sep=",", columns=cols), user_min=umin, item_min=imin))
+        remapped, user2id, item2id = data
+        save["%s_users" % name] = np.array(list(user2id.keys()), np.int64)
+        save["%s_items" % name] = np.array(list(item2id.keys()), np.int64)
+        save["%s_remapped" % name] = table(remapped.copy())
+        for by_time in (True, False):
+            np.random.seed(7)
+            tr, te = split_by_ratio(remapped.copy(), ratio=0.8, by_time=by_time)
+            save["%s_ratio_%d_train" % (name, by_time)], save["%s_ratio_%d_test" % (name, by_time)] = table(tr), table(te)
+            np.random.seed(7)
+            tr, te = split_by_loo(remapped.copy(), by_time=by_time)
+            save["%s_loo_%d_train" % (name, by_time)], save["%s_loo_%d_test" % (name, by_time)] = table(tr), table(te)
+    np.savez_compressed(os.path.join(HERE, "splitter.npz"), **save)
+    print("splitter cases:", len(save))
+
+
 if __name__ == "__main__":
+    if "--only-splitter" in sys.argv:
+        sys.path.insert(0, REF)
+        gen_splitter()
+        sys.exit(0)
     import oracle as orc  # noqa: E402
     os.chdir(REF)        # data/dataset.py paths in tfrec.ini are relative to the tree
     utils, data, evaluator = import_reference()
     ctx = gen_eval(utils, data, evaluator, orc)
     gen_sampler(utils, data, ctx)
     gen_train_steps()
+    gen_splitter()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

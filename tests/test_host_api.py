@@ -128,3 +128,58 @@ def test_checkpoint_round_trip(tmp_path):
     _, epoch, st = load_checkpoint(path)
     assert epoch == 5 and st is None
     assert not [f for f in os.listdir(tmp_path) if "tmp" in f]
+
+
+SPLIT_COLS = ("user", "item", "rating", "time")
+
+
+@pytest.fixture(scope="module")
+def golden_splitter():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "splitter.npz"))
+
+
+@pytest.mark.parametrize("name,umin,imin", [("nofilter", 0, 0), ("filtered", 3, 2)])
+def test_splitter_reproduces_the_reference_splits(golden_splitter, tmp_path, name, umin, imin):
+    """Filtering, re-numbering and the four splits (ratio / leave-one-out, by time / shuffled with numpy's
+    seeded legacy generator) equal what the reference's data/utils.py produced for the same file."""
+    from tfrec_amd.data import splitter as sp_
+    g = golden_splitter
+    path = str(tmp_path / "raw.txt")
+    np.savetxt(path, g["raw"], fmt="%d", delimiter=",")
+    cols = sp_.filter_columns(sp_.load_columns(path, ",", SPLIT_COLS), user_min=umin, item_min=imin)
+    cols, users, items = sp_.remap_columns(cols)
+    assert np.array_equal(users, g[name + "_users"]) and np.array_equal(items, g[name + "_items"])
+    assert np.array_equal(sp_.as_table(cols, SPLIT_COLS), g[name + "_remapped"])
+    for by_time in (True, False):
+        np.random.seed(7)
+        tr, te = sp_.split_by_ratio(cols, ratio=0.8, by_time=by_time)
+        assert np.array_equal(sp_.as_table(tr, SPLIT_COLS), g["%s_ratio_%d_train" % (name, by_time)])
+        assert np.array_equal(sp_.as_table(te, SPLIT_COLS), g["%s_ratio_%d_test" % (name, by_time)])
+        np.random.seed(7)
+        tr, te = sp_.split_by_loo(cols, by_time=by_time)
+        assert np.array_equal(sp_.as_table(tr, SPLIT_COLS), g["%s_loo_%d_train" % (name, by_time)])
+        assert np.array_equal(sp_.as_table(te, SPLIT_COLS), g["%s_loo_%d_test" % (name, by_time)])
+
+
+def test_splitter_files_feed_the_dataset_reader(golden_splitter, tmp_path):
+    """Splitter.split() with the ini-style string config writes the four files; Dataset reads the pair back."""
+    from tfrec_amd.data import Dataset, Splitter
+    path = str(tmp_path / "raw.dat")
+    np.savetxt(path, golden_splitter["raw"], fmt="%d", delimiter=",")
+    cfg = {"data_file": path, "ratio": "0.8", "file_format": "UIRT", "separator": '","', "user_min": "3", "item_min": "2",
+           "by_time": "True", "splitter": "loo"}
+    tr, te = Splitter(cfg).split()
+    g = golden_splitter
+    assert np.array_equal(np.loadtxt(path + ".train", dtype=np.int64, ndmin=2), g["filtered_loo_1_train"])
+    assert np.array_equal(np.loadtxt(path + ".test", dtype=np.int64, ndmin=2), g["filtered_loo_1_test"])
+    u2i = np.loadtxt(path + ".user2id", dtype=np.int64, ndmin=2)
+    assert np.array_equal(u2i[:, 0], g["filtered_users"]) and np.array_equal(u2i[:, 1], np.arange(len(u2i)))
+    ds = Dataset({"data_name": "x", "train_file": path + ".train", "test_file": path + ".test", "format": "UIRT", "separator": "\t"})
+    assert ds.train_matrix.nnz == len(tr["user"]) and ds.test_matrix.nnz == len(te["user"])
+    assert ds.train_matrix.shape == (len(g["filtered_users"]), len(g["filtered_items"]))
+    with pytest.raises(ValueError):
+        Splitter(dict(cfg, splitter="kfold")).split()
+    with pytest.raises(ValueError):
+        Splitter(dict(cfg, file_format="XYZ")).split()
+    with pytest.raises(TypeError):
+        Splitter([("data_file", path)])
