@@ -209,19 +209,40 @@ __device__ __forceinline__ int wave_compact(uint64_t *__restrict__ list, int cnt
     return newc;
 }
 
-// Mid-scan compaction: like wave_compact, but the k survivors are SELECTED, not sorted -- a list only
-// has to be in order when it is written out.  The k-th largest key is found by descending over its
+// Developer build only: per-wave cycle counts of the scan's parts, summed into tf_prof.
+#ifdef TF_EVAL_PROFILE
+__device__ unsigned long long tf_prof[16];
+#define TF_PROF_T() __builtin_readcyclecounter()
+#define TF_PROF_ADD(i, t0) prof_acc[i] += __builtin_readcyclecounter() - (t0)
+extern "C" int tfrec_debug_prof(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tf_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(tf_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define TF_PROF_T() 0ull
+#define TF_PROF_ADD(i, t0) (void)(t0)
+#endif
+
+// Compaction by selection: like wave_compact, but the k survivors are SELECTED, not sorted -- a list
+// only has to be in order when it is written out, and then only its k survivors (wave_finish).  The k-th largest key is found by descending over its
 // bits (one wave-uniform count per bit: compares, ballots and scalar population counts; the low
 // half -- the id -- only when scores tie at the cut), which costs an order of magnitude fewer
 // vector instructions than the sort.  The survivors are written back in lane order.
-template <int CAP>
-__device__ __forceinline__ int wave_select(uint64_t *__restrict__ list, int cnt, int ver, int k,
+template <int CAP, class Out>
+__device__ __forceinline__ int wave_select(const uint64_t *list, int cnt, int ver, int k,
                                            const int32_t *__restrict__ mask_idx, int64_t mlo, int64_t mhi,
-                                           volatile uint64_t *sortbuf, int lane, float *tau_out)
+                                           volatile uint64_t *sortbuf, int lane, float *tau_out, Out out,
+                                           [[maybe_unused]] unsigned long long *prof_acc = nullptr)
 {
+    [[maybe_unused]] unsigned long long prof_t = TF_PROF_T();
     constexpr int EPL = CAP / 64;
     constexpr int ROWCAP = CAP * 2;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#ifdef TF_EVAL_PROFILE
+    if (prof_acc) { prof_acc[8] += TF_PROF_T() - prof_t; prof_t = TF_PROF_T(); }
+#endif
     const int64_t L = mhi - mlo;
     const bool check = mask_idx != nullptr && L > 0 && ver < cnt;
     const bool staged = check && L <= ROWCAP;
@@ -232,12 +253,37 @@ __device__ __forceinline__ int wave_select(uint64_t *__restrict__ list, int cnt,
         const int e = lane + 64 * q;
         keys[q] = e < cnt ? list[e] : 0;
     }
+    // short rows are padded to whole groups of four with an id no key carries
+    constexpr int LINEAR_MAX = 64;
+    const bool linear = staged && L <= LINEAR_MAX;
     if (staged) {
-        for (int j = lane; j < (int)L; j += 64) rowbuf[j] = mask_idx[mlo + j];
+        const int Lp = linear ? (((int)L + 3) & ~3) : (int)L;
+        for (int j = lane; j < Lp; j += 64) rowbuf[j] = j < (int)L ? mask_idx[mlo + j] : -2;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    if (check) {
+#ifdef TF_EVAL_PROFILE
+    if (prof_acc) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); prof_acc[9] += TF_PROF_T() - prof_t; prof_t = TF_PROF_T(); }
+#endif
+    if (linear) {
+        // every row id against every held id: the row is read four ids at a time (all lanes the same
+        // address, one LDS access), independent reads instead of a chain of dependent probes per key
+        const int4 *row4 = reinterpret_cast<const int4 *>(const_cast<const int32_t *>(rowbuf));
+        bool hit[EPL];
+#pragma unroll
+        for (int q = 0; q < EPL; ++q) hit[q] = false;
+        for (int j = 0; j < (int)L; j += 4) {
+            const int4 r = row4[j >> 2];
+#pragma unroll
+            for (int q = 0; q < EPL; ++q) {
+                const int32_t id = key_id(keys[q]);
+                hit[q] = hit[q] | (id == r.x) | (id == r.y) | (id == r.z) | (id == r.w);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < EPL; ++q)
+            if (hit[q]) keys[q] = 0;
+    } else if (check) {
 #pragma unroll
         for (int q = 0; q < EPL; ++q) {
             const int e = lane + 64 * q;
@@ -262,46 +308,113 @@ __device__ __forceinline__ int wave_select(uint64_t *__restrict__ list, int cnt,
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();          // every lane is done with the staged row
+#ifdef TF_EVAL_PROFILE
+    if (prof_acc) { prof_acc[10] += TF_PROF_T() - prof_t; prof_t = TF_PROF_T(); }
+#endif
     int kept = 0;
 #pragma unroll
     for (int q = 0; q < EPL; ++q) kept += __popcll(__ballot(keys[q] != 0));
     uint64_t cut = 1;                          // keep every real key while fewer than k are held
     if (kept >= k) {
-        uint32_t hi_cut = 0;
-#pragma unroll 1
-        for (int bit = 31; bit >= 0; --bit) {
-            const uint32_t t2 = hi_cut | (1u << bit);
-            int c = 0;
+        // the bits all held scores share need no descent: start below the highest bit in which they differ
+        uint32_t all_or = 0, all_and = 0xffffffffu;
 #pragma unroll
-            for (int q = 0; q < EPL; ++q) c += __popcll(__ballot((uint32_t)(keys[q] >> 32) >= t2));
-            if (c >= k) hi_cut = t2;
+        for (int q = 0; q < EPL; ++q) {
+            const uint32_t hi = (uint32_t)(keys[q] >> 32);
+            all_or |= hi;
+            all_and &= keys[q] != 0 ? hi : 0xffffffffu;
+        }
+        all_or |= xor_lane_u32<32>(all_or, lane);  all_and &= xor_lane_u32<32>(all_and, lane);
+        all_or |= xor_lane_u32<16>(all_or, lane);  all_and &= xor_lane_u32<16>(all_and, lane);
+        all_or |= xor_lane_u32<8>(all_or, lane);   all_and &= xor_lane_u32<8>(all_and, lane);
+        all_or |= xor_lane_u32<4>(all_or, lane);   all_and &= xor_lane_u32<4>(all_and, lane);
+        all_or |= xor_lane_u32<2>(all_or, lane);   all_and &= xor_lane_u32<2>(all_and, lane);
+        all_or |= xor_lane_u32<1>(all_or, lane);   all_and &= xor_lane_u32<1>(all_and, lane);
+        const uint32_t differ = __builtin_amdgcn_readfirstlane(all_or ^ all_and);
+        // highest differing bit, moved up to an odd position so that whole pairs of bits remain (a shared
+        // bit taken into the descent is simply found again)
+        int bit = differ ? ((31 - __builtin_clz(differ)) | 1) : -1;
+        uint32_t hi_cut = __builtin_amdgcn_readfirstlane(all_and) & (bit >= 0 ? ~(uint32_t)((2ull << bit) - 1ull) : 0xffffffffu);
+        bool exact = false;
+        const bool may_stop = kept > k;        // with exactly k held, all bits are resolved: the cut is then the lowest score
+        // two bits per round: three counts, then the largest candidate that still has k keys at or above it
+#pragma unroll 1
+        for (; bit >= 1; bit -= 2) {
+            const uint32_t step = 1u << (bit - 1);
+            const uint32_t t1 = hi_cut + step, t2 = hi_cut + 2 * step, t3 = hi_cut + 3 * step;
+            int c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+            for (int q = 0; q < EPL; ++q) {
+                const uint32_t hi = (uint32_t)(keys[q] >> 32);
+                c1 += __popcll(__ballot(hi >= t1));
+                c2 += __popcll(__ballot(hi >= t2));
+                c3 += __popcll(__ballot(hi >= t3));
+            }
+            const bool g3 = c3 >= k, g2 = c2 >= k, g1 = c1 >= k;
+            const uint32_t sel = g3 ? 3u : (g2 ? 2u : (g1 ? 1u : 0u));
+            const int cs = g3 ? c3 : (g2 ? c2 : c1);
+            hi_cut += sel * step;
+            exact = sel ? cs == k : exact;
+            if (exact && may_stop) break;
         }
         cut = (uint64_t)hi_cut << 32;
-        int c = 0;
-#pragma unroll
-        for (int q = 0; q < EPL; ++q) c += __popcll(__ballot(keys[q] >= cut));
-        if (c > k) {                           // equal scores straddle the cut: the id decides
+        if (!exact) {                          // equal scores may straddle the cut: the id decides
 #pragma unroll 1
             for (int bit = 31; bit >= 0; --bit) {
                 const uint64_t t2 = cut | (1ull << bit);
                 int c2 = 0;
 #pragma unroll
                 for (int q = 0; q < EPL; ++q) c2 += __popcll(__ballot(keys[q] >= t2));
-                if (c2 >= k) cut = t2;
+                if (c2 >= k) {
+                    cut = t2;
+                    if (c2 == k) break;
+                }
             }
         }
     }
+#ifdef TF_EVAL_PROFILE
+    if (prof_acc) { prof_acc[11] += TF_PROF_T() - prof_t; prof_t = TF_PROF_T(); }
+#endif
     int base = 0;
 #pragma unroll
     for (int q = 0; q < EPL; ++q) {
         const bool keep = keys[q] >= cut;
         const uint64_t m = __ballot(keep);
-        if (keep) list[base + __popcll(m & ((1ull << lane) - 1ull))] = keys[q];
+        if (keep) out[base + __popcll(m & ((1ull << lane) - 1ull))] = keys[q];
         base += __popcll(m);
     }
     *tau_out = kept >= k ? key_score(cut) : -INFINITY;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#ifdef TF_EVAL_PROFILE
+    if (prof_acc) { prof_acc[12] += TF_PROF_T() - prof_t; }
+#endif
     return base;
+}
+
+// End of the scan: select the k survivors into the wave's LDS buffer (the staged row is no longer
+// needed once the selection has its keys in registers), sort just those, leave them in sortbuf[0..n).
+template <int CAP>
+__device__ __forceinline__ int wave_finish(const uint64_t *__restrict__ list, int cnt, int ver, int k,
+                                           const int32_t *__restrict__ mask_idx, int64_t mlo, int64_t mhi,
+                                           volatile uint64_t *sortbuf, int lane)
+{
+    constexpr int SN = CAP / 2;               // k <= CAP/2 - 16 for every capacity in use
+    float tau;
+    const int nc = wave_select<CAP>(list, cnt, ver, k, mask_idx, mlo, mhi, sortbuf, lane, &tau, sortbuf);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint64_t keys[SN / 64];
+#pragma unroll
+    for (int q = 0; q < SN / 64; ++q) {
+        const int e = lane + 64 * q;
+        keys[q] = e < nc ? sortbuf[e] : 0;
+    }
+    bitonic_sort<SN, SN>(keys, lane);
+#pragma unroll
+    for (int q = 0; q < SN / 64; ++q) sortbuf[lane + 64 * q] = keys[q];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return nc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -362,6 +475,13 @@ struct ScoreGeom {
 template <int D, bool BF16, int CAP>
 struct ScoreWave { static constexpr int UW = 1; };
 
+// Developer ablations of the scan loop (never defined in the shipped build): 1 = no list filter,
+// 2 = also no LDS fragment reads, 3 = also no tile staging, 4 = also no final pass, 5 = also no
+// per-tile maximum.
+#ifndef TF_EVAL_ABLATE
+#define TF_EVAL_ABLATE 0
+#endif
+
 template <int D, bool BF16, int CAP>
 __global__ __launch_bounds__(256) void score_topk_kernel(ScoreArgs a)
 {
@@ -375,6 +495,8 @@ __global__ __launch_bounds__(256) void score_topk_kernel(ScoreArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int uj = lane & 31, h = lane >> 5;
+    [[maybe_unused]] unsigned long long prof_acc[16] = {};
+    [[maybe_unused]] const unsigned long long prof_t_start = TF_PROF_T();
     const int64_t wave_user0 = (int64_t)blockIdx.x * UB + wave * 32 * UW;   // first evaluated-user ordinal of the wave
     const int64_t it0 = (int64_t)blockIdx.y * a.split_items;             // first item (shard-relative)
     const int64_t it1 = it0 + a.split_items < a.n_items ? it0 + a.split_items : a.n_items;
@@ -456,7 +578,7 @@ __global__ __launch_bounds__(256) void score_topk_kernel(ScoreArgs a)
     const int64_t n_steps = (it1 - it0 + TI - 1) / TI;
     for (int64_t step = 0; step < n_steps; ++step) {
         const int buf = (int)(step & 1);
-        if (step + 1 < n_steps) load_tile(it0 + (step + 1) * TI);
+        if (TF_EVAL_ABLATE < 3 && step + 1 < n_steps) load_tile(it0 + (step + 1) * TI);
         const char *qb = qbuf + buf * G::QBYTES;
         const float *bb = bias + buf * TI;
 #pragma unroll 1
@@ -474,7 +596,7 @@ __global__ __launch_bounds__(256) void score_topk_kernel(ScoreArgs a)
             if constexpr (BF16) {
 #pragma unroll
                 for (int ks = 0; ks < D / 16; ++ks) {
-                    const bf16x8 av = *reinterpret_cast<const bf16x8 *>(arow + (16 * ks + 8 * h) * 2);
+                    const bf16x8 av = TF_EVAL_ABLATE >= 2 ? pb[0][ks] : *reinterpret_cast<const bf16x8 *>(arow + (16 * ks + 8 * h) * 2);
 #pragma unroll
                     for (int s = 0; s < UW; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pb[s][ks], acc[s], 0, 0, 0);
                 }
@@ -495,12 +617,22 @@ __global__ __launch_bounds__(256) void score_topk_kernel(ScoreArgs a)
                 // epilogue: filter the lane's 16 items against its user's threshold.  Passing scores are
                 // rare per lane but not per wave, so every test is first made wave-uniform (a scalar
                 // branch on a ballot): groups of four by their maximum, then the members of a group.
+                if (TF_EVAL_ABLATE >= 5) {
+                    if (acc[s][0] == 12345.678f) mylist[s][0] = make_key(acc[s][5], id0);
+                    continue;
+                }
                 float gm[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     gm[g] = fmaxf(fmaxf(acc[s][4 * g], acc[s][4 * g + 1]), fmaxf(acc[s][4 * g + 2], acc[s][4 * g + 3]));
                 const float mx = fmaxf(fmaxf(gm[0], gm[1]), fmaxf(gm[2], gm[3]));
+                if (TF_EVAL_ABLATE >= 1) {
+                    if (mx == 12345.678f) mylist[s][0] = make_key(mx, id0);
+                    continue;
+                }
+                [[maybe_unused]] const unsigned long long prof_t_ins = TF_PROF_T();
                 if (__ballot(mx > th[s]) != 0) {
+                    prof_acc[4] += 1;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         if (__ballot(gm[g] > th[s]) != 0) {
@@ -517,9 +649,12 @@ __global__ __launch_bounds__(256) void score_topk_kernel(ScoreArgs a)
                         }
                     }
                 }
+                TF_PROF_ADD(1, prof_t_ins);
                 // a list that could overflow during the next 32 items is compacted now
                 uint64_t need = __ballot(lane < 32 && mycnt[s] > CAP - 32);
+                [[maybe_unused]] const unsigned long long prof_t_cmp = TF_PROF_T();
                 while (need) {
+                    prof_acc[5] += 1;
                     const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(need));
                     need &= need - 1;
                     const int64_t sur = wave_user0 + s * 32 + src;
@@ -527,16 +662,23 @@ __global__ __launch_bounds__(256) void score_topk_kernel(ScoreArgs a)
                     const int64_t slo = __shfl(mlo[s], src, 64), shi = __shfl(mhi[s], src, 64);
                     float nt;
                     const int nc = wave_select<CAP>(sl, __builtin_amdgcn_readlane(mycnt[s], src), __builtin_amdgcn_readlane(myver[s], src),
-                                                    a.k, a.train_indices, slo, shi, mysort, lane, &nt);
+                                                    a.k, a.train_indices, slo, shi, mysort, lane, &nt, sl, prof_acc);
                     if (uj == src) { mycnt[s] = nc; myver[s] = nc; th[s] = nt; }
                 }
+                TF_PROF_ADD(2, prof_t_cmp);
             }
         }
-        if (step + 1 < n_steps) store_tile(buf ^ 1);
-        __syncthreads();
+        if (TF_EVAL_ABLATE < 3) {
+            [[maybe_unused]] const unsigned long long prof_t_bar = TF_PROF_T();
+            if (step + 1 < n_steps) store_tile(buf ^ 1);
+            __syncthreads();
+            TF_PROF_ADD(3, prof_t_bar);
+        }
     }
+    [[maybe_unused]] const unsigned long long prof_t_fin = TF_PROF_T();
 
     // final compaction and output: the wave's users one after the other
+    if (TF_EVAL_ABLATE >= 4) return;
 #pragma unroll
     for (int s = 0; s < UW; ++s) {
         for (int src = 0; src < 32; ++src) {
@@ -544,9 +686,8 @@ __global__ __launch_bounds__(256) void score_topk_kernel(ScoreArgs a)
             if (sur >= a.n) break;     // wave-uniform
             uint64_t *sl = a.lists + ((size_t)blockIdx.y * a.n + sur) * CAP;
             const int64_t slo = __shfl(mlo[s], src, 64), shi = __shfl(mhi[s], src, 64);
-            float nt;
-            const int nc = wave_compact<CAP>(sl, __builtin_amdgcn_readlane(mycnt[s], src), __builtin_amdgcn_readlane(myver[s], src), a.k,
-                                             a.train_indices, slo, shi, mysort, lane, &nt);
+            const int nc = wave_finish<CAP>(sl, __builtin_amdgcn_readlane(mycnt[s], src), __builtin_amdgcn_readlane(myver[s], src), a.k,
+                                            a.train_indices, slo, shi, mysort, lane);
             int32_t *oi = a.out_ids + ((size_t)blockIdx.y * a.n + sur) * a.k;
             float *os = a.out_scores + ((size_t)blockIdx.y * a.n + sur) * a.k;
             for (int e = lane; e < a.k; e += 64) {
@@ -557,6 +698,13 @@ __global__ __launch_bounds__(256) void score_topk_kernel(ScoreArgs a)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
+#ifdef TF_EVAL_PROFILE
+    TF_PROF_ADD(6, prof_t_fin);
+    TF_PROF_ADD(0, prof_t_start);
+    if (lane == 0)
+        for (int i = 0; i < 16; ++i) if (i != 7) atomicAdd(&tf_prof[i], prof_acc[i]);
+    if (lane == 0) atomicAdd(&tf_prof[7], 1ull);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

@@ -41,12 +41,22 @@ def main():
     mode = SCORE_BF16 if a.mode == "bf16" else SCORE_F32
     dev.score_topk(P, Q, b, eu, a.k, train=(indptr, indices), mode=mode, out_ids=ids, out_scores=sc)
     torch.cuda.synchronize()
+    import ctypes
+    prof = getattr(dev.lib, "tfrec_debug_prof", None) if hasattr(dev.lib, "tfrec_debug_prof") else None
+    buf = (ctypes.c_ulonglong * 16)()
+    if prof is not None:
+        prof(buf, 1)
     for _ in range(a.reps):
         t0 = time.perf_counter()
         dev.score_topk(P, Q, b, eu, a.k, train=(indptr, indices), mode=mode, out_ids=ids, out_scores=sc)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         fl = 2.0 * a.I * a.d * n / dt
+        if prof is not None:
+            prof(buf, 1)
+            w = max(buf[7], 1)
+            names = ["total", "filter+insert", "compaction", "store+barrier", "passing tiles", "compactions", "final", "waves", "c.fence", "c.load", "c.check", "c.descent", "c.write"]
+            print("  per wave: " + ", ".join(f"{nm}={buf[i] / w:,.0f}" for i, nm in enumerate(names)), flush=True)
         print(f"eval {a.mode} {a.model}: {n} users x {a.I} items d={a.d} k={a.k}: {dt*1e3:.2f} ms  {n/dt:,.0f} users/s  {fl/1e12:.1f} TFLOP/s", flush=True)
 
 
