@@ -159,7 +159,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1 << 20, help="triples per step per GPU")
+    ap.add_argument("--batch", type=int, default=1 << 22, help="triples per step per GPU")
     ap.add_argument("--users", type=int, default=1_000_000)
     ap.add_argument("--items", type=int, default=200_000)
     ap.add_argument("--factors", type=int, default=64)
