@@ -6,14 +6,16 @@
 One "step" is one BPR-MF minibatch step (gather, dot, pairwise loss forward/backward, duplicate
 reduction, SGD row updates) over one batch of synthetic triples that is already resident in
 HBM.  N=1 runs the single-GPU configuration the metric is quoted on (1M users x 200k items,
-d=64, fp32); N>1 (launched by torch.distributed.run, one rank per GPU) runs the row-sharded
-tables with an all-to-all exchange of item rows and gradients per step, weak scaling (the
+d=64, fp32); N>1 (launched by torch.distributed.run, one rank per GPU) shards the user table by
+rows; the item table (51 MB here) is replicated and the item-gradient sums are all-reduced once per
+step (item tables above 256 MB are row-sharded too, with all-to-all lookups); weak scaling (the
 per-GPU batch is fixed).  Rank 0 prints ONE JSON line.
 
-Extra objects on that line: "other_paths" (APR step and DNS selection on the same tables), "roofline" (the step's kernels against the HBM roofline, timed
-with HIP events on the stream the library launches on), "cpu_baseline" (the CPU oracle timed
-on this host, rank 0, N=1 only) and "eval" (full-rank evaluation users/s, timed separately,
-outside the K training steps).
+Extra objects on that line: "roofline" (the step's kernels against the HBM roofline, timed with HIP
+events on the stream the library launches on), "cpu_baseline" (the CPU oracle timed on this host,
+rank 0, N=1 only), "eval" (full-rank evaluation users/s against the MFMA roofline, timed separately,
+outside the K training steps, with its own "cpu_baseline": the reference's C++ evaluator on a bounded
+user sample) and "other_paths" (APR step, DNS selection and the device epoch pipeline on the same tables).
 """
 import argparse
 import json
@@ -152,6 +154,42 @@ def cpu_baseline(U, I, d, B, lr, reg, budget_s=12.0):
     return {"value": done / t_used, "unit": "triples/s", "cores": 1, "kind": "port",
             "sample": "%d steps of %d triples on the same %dx%d d=%d tables (oracle/mf_oracle.c, scalar C, step math only)"
                       % (steps, B, U, I, d)}
+
+
+def cpu_baseline_eval(I, d, k, n_users=1024, threads=16):
+    """Full-rank evaluation of a bounded user sample on the host: the reference's own C++ top-k and metrics
+    (compiled from its sources into oracle/_ref, evaluator/backend/cpp/tools.h:10-30, evaluate.h:13-93) behind
+    the dense numpy scoring of model/BPR.py:76-80, when that library is present; else the single-thread C
+    restatement."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    rng = np.random.default_rng(7)
+    P = rng.uniform(-0.05, 0.05, (n_users, d)).astype(np.float32)
+    Q = rng.uniform(-0.05, 0.05, (I, d)).astype(np.float32)
+    b = rng.normal(size=I).astype(np.float32)
+    deg, tdeg = 20, 3
+    train = np.sort(rng.integers(0, I, (n_users, deg)), axis=1).astype(np.int32)
+    test = [np.unique(rng.integers(0, I, tdeg)).astype(np.int32) for _ in range(n_users)]
+    if orc.ref_lib() is not None:
+        t0 = time.perf_counter()
+        R = np.matmul(P, Q.T) + b
+        np.put_along_axis(R, train.astype(np.int64), -np.inf, axis=1)
+        ranks = orc.ref_topk_rows(R, k, threads=threads)
+        orc.ref_evaluate(ranks, test, threads=threads)
+        dt = time.perf_counter() - t0
+        return {"value": n_users / dt, "unit": "users/s", "cores": threads, "kind": "reference",
+                "sample": "%d users x %d items, d=%d, k=%d: numpy scoring + the reference's C++ top-k and metrics (oracle/_ref), %d threads"
+                          % (n_users, I, d, k, threads)}
+    n_users = min(n_users, 128)
+    tptr = np.arange(0, deg * (n_users + 1), deg, dtype=np.int64)
+    eptr = np.zeros(n_users + 1, np.int64)
+    eptr[1:] = np.cumsum([len(t) for t in test[:n_users]])
+    t0 = time.perf_counter()
+    orc.eval_fullrank(P[:n_users], Q, b, np.arange(n_users, dtype=np.int32), (tptr, train[:n_users].ravel()),
+                      (eptr, np.concatenate(test[:n_users])), k, score_mode=0)
+    dt = time.perf_counter() - t0
+    return {"value": n_users / dt, "unit": "users/s", "cores": 1, "kind": "port",
+            "sample": "%d users x %d items, d=%d, k=%d (oracle/mf_oracle.c, scalar C)" % (n_users, I, d, k)}
 
 
 def main():
@@ -434,6 +472,8 @@ def main():
                 out["other_paths"] = other_paths(dev, P, Q, b, U, I, d, B, gen, cuda)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(U, I, d, 1 << 17, lr, reg)
+                if "eval" in out:
+                    out["eval"]["cpu_baseline"] = cpu_baseline_eval(I, d, args.topk)
         if rank == 0:
             print(json.dumps(out), flush=True)
     if world > 1:
