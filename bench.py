@@ -349,64 +349,76 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": per_gpu, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per_gpu / HBM_PEAK_GBS,
                                "traffic": None, "kernel": "per GPU: one BPR step incl. the item-gradient exchange",
                                "algorithmic_bytes_per_triple": alg_bytes_per_triple}
+        def guarded(name, fn):
+            """Secondary measurements must not cost the headline line: a failure is reported in their place."""
+            try:
+                out[name] = fn()
+            except Exception as e:      # noqa: BLE001 -- reported, not swallowed
+                out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+
         if trainer is not None and not args.no_eval:
-            # full-rank evaluation over the ranks, eval_users per GPU (weak scaling).  Replicated item table:
-            # every rank evaluates the users it owns against all items.  Sharded item table: every rank scores
-            # its item range for all evaluated users (factors broadcast from the owner), lists gathered and merged.
-            from tfrec_amd.sharded import ShardedEvaluator
-            g2 = torch.Generator(device=cuda)
-            g2.manual_seed(4242)                                   # the same interaction lists on every rank
-            n, k = min(args.eval_users * world, U), args.topk
-            eu = (torch.arange(n, device=cuda, dtype=torch.int64) * U // n).to(torch.int32)     # spread evenly over the owners
-            deg, tdeg = 20, 3
-            indptr = torch.arange(0, deg * (U + 1), deg, device=cuda, dtype=torch.int64)
-            indices = torch.sort(torch.randint(0, I, (U, deg), device=cuda, generator=g2, dtype=torch.int32), dim=1).values.reshape(-1).contiguous()
-            tptr = torch.arange(0, tdeg * (U + 1), tdeg, device=cuda, dtype=torch.int64)
-            tidx = torch.sort(torch.randint(0, I, (U, tdeg), device=cuda, generator=g2, dtype=torch.int32), dim=1).values.reshape(-1).contiguous()
-            ev = {}
-            for mode, name in ((SCORE_F32, "f32"), (SCORE_BF16, "bf16")):
-                se = ShardedEvaluator(dev, trainer, (indptr, indices), (tptr, tidx), eu, top_k=k, mode=mode)
-                se.evaluate()                                      # warm-up, sizes the workspaces
+            def sharded_eval():
+                # full-rank evaluation over the ranks, eval_users per GPU (weak scaling).  Replicated item table:
+                # every rank evaluates the users it owns against all items.  Sharded item table: every rank scores
+                # its item range for all evaluated users (factors broadcast from the owner), lists gathered and merged.
+                from tfrec_amd.sharded import ShardedEvaluator
+                g2 = torch.Generator(device=cuda)
+                g2.manual_seed(4242)                                   # the same interaction lists on every rank
+                n, k = min(args.eval_users * world, U), args.topk
+                eu = (torch.arange(n, device=cuda, dtype=torch.int64) * U // n).to(torch.int32)     # spread evenly over the owners
+                deg, tdeg = 20, 3
+                indptr = torch.arange(0, deg * (U + 1), deg, device=cuda, dtype=torch.int64)
+                indices = torch.sort(torch.randint(0, I, (U, deg), device=cuda, generator=g2, dtype=torch.int32), dim=1).values.reshape(-1).contiguous()
+                tptr = torch.arange(0, tdeg * (U + 1), tdeg, device=cuda, dtype=torch.int64)
+                tidx = torch.sort(torch.randint(0, I, (U, tdeg), device=cuda, generator=g2, dtype=torch.int32), dim=1).values.reshape(-1).contiguous()
+                ev = {}
+                for mode, name in ((SCORE_F32, "f32"), (SCORE_BF16, "bf16")):
+                    se = ShardedEvaluator(dev, trainer, (indptr, indices), (tptr, tidx), eu, top_k=k, mode=mode)
+                    se.evaluate()                                      # warm-up, sizes the workspaces
+                    barrier()
+                    t1 = time.perf_counter()
+                    se.evaluate()
+                    barrier()
+                    dt = time.perf_counter() - t1
+                    if world > 1:
+                        tm = torch.tensor([dt], device=cuda, dtype=torch.float64)
+                        torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
+                        dt = float(tm.item())
+                    tf = 2.0 * I * d * n / dt / 1e12
+                    ev[name] = {"users_per_s": n / dt, "ms": dt * 1e3, "users": n, "items": I, "topk": k, "layout": se.layout + "-sharded",
+                                "roofline": {"bound": "mfma", "achieved": tf / world, "peak": MFMA_PEAK_TFLOPS[name], "unit": "TFLOP/s per GPU",
+                                             "frac": tf / world / MFMA_PEAK_TFLOPS[name]}}
+                return ev
+            guarded("eval", sharded_eval)
+        if trainer is not None and not args.no_other:
+            def sharded_apr():
+                # the APR step over the ranks (conf/APR.ini): user tables sharded, item tables replicated, two
+                # all-reduces of item-gradient sums per step
+                from tfrec_amd.sharded import ShardedAprTrainer
+                apr = ShardedAprTrainer(dev, U, I, d, 0.05, 0.0, 1.0, 0.05, seed=2018, device=cuda)
+                for s in range(3):
+                    apr.step(*batch(s), global_batch=B * world)
                 barrier()
                 t1 = time.perf_counter()
-                se.evaluate()
+                apr_steps = 10
+                for s in range(apr_steps):
+                    apr.step(*batch(3 + s), global_batch=B * world)
                 barrier()
                 dt = time.perf_counter() - t1
                 if world > 1:
                     tm = torch.tensor([dt], device=cuda, dtype=torch.float64)
                     torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
                     dt = float(tm.item())
-                tf = 2.0 * I * d * n / dt / 1e12
-                ev[name] = {"users_per_s": n / dt, "ms": dt * 1e3, "users": n, "items": I, "topk": k, "layout": se.layout + "-sharded",
-                            "roofline": {"bound": "mfma", "achieved": tf / world, "peak": MFMA_PEAK_TFLOPS[name], "unit": "TFLOP/s per GPU",
-                                         "frac": tf / world / MFMA_PEAK_TFLOPS[name]}}
-            out["eval"] = ev
-        if trainer is not None and not args.no_other:
-            # the APR step over the ranks (conf/APR.ini): user tables sharded, item tables replicated, two
-            # all-reduces of item-gradient sums per step
-            from tfrec_amd.sharded import ShardedAprTrainer
-            apr = ShardedAprTrainer(dev, U, I, d, 0.05, 0.0, 1.0, 0.05, seed=2018, device=cuda)
-            for s in range(3):
-                apr.step(*batch(s), global_batch=B * world)
-            barrier()
-            t1 = time.perf_counter()
-            apr_steps = 10
-            for s in range(apr_steps):
-                apr.step(*batch(3 + s), global_batch=B * world)
-            barrier()
-            dt = time.perf_counter() - t1
-            if world > 1:
-                tm = torch.tensor([dt], device=cuda, dtype=torch.float64)
-                torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
-                dt = float(tm.item())
-            apr_bytes = 84 * d + 68
-            per_gpu = B * apr_bytes / (dt / apr_steps) / 1e9
-            out["other_paths"] = {"apr_adagrad_step": {
-                "triples_per_s": world * B * apr_steps / dt, "ms_per_step": dt * 1e3 / apr_steps, "batch_per_gpu": B,
-                "parallelism": "user tables row-sharded over %d GPUs, item tables replicated, two all-reduces per step" % world,
-                "roofline": {"bound": "hbm", "achieved": per_gpu, "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU", "frac": per_gpu / HBM_PEAK_GBS,
-                             "algorithmic_bytes_per_triple": apr_bytes}}}
-            del apr
+                apr_bytes = 84 * d + 68
+                per_gpu = B * apr_bytes / (dt / apr_steps) / 1e9
+                res = {"apr_adagrad_step": {
+                    "triples_per_s": world * B * apr_steps / dt, "ms_per_step": dt * 1e3 / apr_steps, "batch_per_gpu": B,
+                    "parallelism": "user tables row-sharded over %d GPUs, item tables replicated, two all-reduces per step" % world,
+                    "roofline": {"bound": "hbm", "achieved": per_gpu, "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU", "frac": per_gpu / HBM_PEAK_GBS,
+                                 "algorithmic_bytes_per_triple": apr_bytes}}}
+                del apr
+                return res
+            guarded("other_paths", sharded_apr)
         if rank == 0 and world == 1 and not args.force_sharded:
             # ---- roofline of the step's kernels: HIP events recorded by the library on its own stream
             # (un-pipelined steps, so that the index phase is timed on the same stream as the row passes)
