@@ -284,3 +284,61 @@ def test_axpy_and_dense_grad_step_contract(dev):
         dev.bpr_dense_grad_step(dP, dQ, db, G, dev.array(u), dev.array(i), dev.array(j), 0.01, 0.05, slot=5)
     with pytest.raises(ValueError):
         dev.bpr_dense_grad_step(dP, dQ, db, G, None, None, None, 0.01, 0.05, slot=0)     # nothing prepared in slot 0
+
+
+def test_full_size_step_against_float64_index_add(dev):
+    """The bench workload at its full size (1M users x 200k items, d=64, 4M triples, Zipf positives): every
+    row of P, Q and b after one step against an independent float64 statement of model/BPR.py:36-48 built
+    from torch gathers and index_add_ on the same device, plus two size-independent properties: a step with
+    lr = 0 leaves every parameter bit for bit, and without regularisation the biases only move mass between
+    items (each triple takes s from its negative's bias gradient and gives it to its positive's)."""
+    import torch
+    from tfrec_amd.device import Device
+    cuda = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=cuda)
+    with torch.cuda.stream(stream):
+        d2 = Device(0, stream=stream.cuda_stream)
+        U, I, d, B, lr, reg = 1_000_000, 200_000, 64, 1 << 22, 0.01, 0.05
+        g = torch.Generator(device=cuda); g.manual_seed(99)
+        P = (torch.rand(U, d, device=cuda, generator=g) - 0.5) * 0.6
+        Q = (torch.rand(I, d, device=cuda, generator=g) - 0.5) * 0.6
+        b = torch.randn(I, device=cuda, generator=g) * 0.1
+        u = torch.randint(0, U, (B,), device=cuda, generator=g, dtype=torch.int32)
+        w = 1.0 / torch.arange(1, I + 1, device=cuda, dtype=torch.float64)
+        cdf = torch.cumsum(w, 0) / w.sum()
+        i = torch.searchsorted(cdf, torch.rand(B, device=cuda, generator=g, dtype=torch.float64)).clamp_(max=I - 1).to(torch.int32)
+        j = torch.randint(0, I, (B,), device=cuda, generator=g, dtype=torch.int32)
+
+        def reference(reg_):
+            ul, il, jl = u.long(), i.long(), j.long()
+            p, qi, qj = P[ul].double(), Q[il].double(), Q[jl].double()
+            z = (p * (qi - qj)).sum(1) + (b[il].double() - b[jl].double()) + 1e-7
+            s = torch.sigmoid(-z)
+            gP = torch.zeros(U, d, device=cuda, dtype=torch.float64).index_add_(0, ul, -s[:, None] * (qi - qj) + reg_ * p)
+            gQ = torch.zeros(I, d, device=cuda, dtype=torch.float64)
+            gQ.index_add_(0, il, -s[:, None] * p + reg_ * qi).index_add_(0, jl, s[:, None] * p + reg_ * qj)
+            gb = torch.zeros(I, device=cuda, dtype=torch.float64)
+            gb.index_add_(0, il, -s + reg_ * b[il].double()).index_add_(0, jl, s + reg_ * b[jl].double())
+            return P.double() - lr * gP, Q.double() - lr * gQ, b.double() - lr * gb
+
+        P1, Q1, b1 = P.clone(), Q.clone(), b.clone()
+        d2.bpr_sgd_step(P1, Q1, b1, u, i, j, lr, reg)
+        d2.synchronize()
+        for got, want in zip((P1, Q1, b1), reference(reg)):
+            err = (got.double() - want).abs()
+            tol = ATOL + RTOL * want.abs()
+            # hot items sum tens of thousands of float32 terms: their error is bounded relative to the row, not the entry
+            row_scale = want.abs().amax(dim=-1, keepdim=True) if want.dim() == 2 else want.abs()
+            assert bool((err <= tol + RTOL * row_scale).all()), float((err - tol).max())
+        # lr = 0: nothing moves
+        P2, Q2, b2 = P.clone(), Q.clone(), b.clone()
+        d2.bpr_sgd_step(P2, Q2, b2, u, i, j, 0.0, reg)
+        d2.synchronize()
+        assert torch.equal(P2, P) and torch.equal(Q2, Q) and torch.equal(b2, b)
+        # reg = 0: the bias gradients of a step sum to zero
+        P3, Q3, b3 = P.clone(), Q.clone(), b.clone()
+        d2.bpr_sgd_step(P3, Q3, b3, u, i, j, lr, 0.0)
+        d2.synchronize()
+        moved = (b3.double() - b.double())
+        assert abs(float(moved.sum())) <= 1e-5 * float(moved.abs().sum())
+        d2.close()

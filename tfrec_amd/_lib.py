@@ -4,7 +4,9 @@ There is no CPU fallback: if the library is missing or does not load, importing 
 product path fails with an ImportError that says how to build it.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # TFREC_AMD_LIB names another build of the same library (kernel tuning experiments)
@@ -75,11 +77,35 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """A process can drive the GPU through ONE HIP runtime only.  PyTorch-ROCm wheels bundle their own
+    libamdhip64 (same soname as the system one): when torch is imported first, this library binds to that
+    copy and both work; when this library came first it used to bind to the system runtime, and torch's
+    later initialisation then found no GPU.  So if a torch with a bundled runtime is installed (imported
+    or not -- it is not imported here), that runtime is loaded before ours, which makes the order of the
+    imports irrelevant.  TFREC_AMD_SYSTEM_HIP=1 skips this."""
+    if os.environ.get("TFREC_AMD_SYSTEM_HIP") == "1" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Loads the shared library once and attaches the signatures."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "%s is missing: build it with `make -C tfrec_amd/csrc -j8` (hipcc, gfx950) or "
