@@ -286,10 +286,27 @@ def test_axpy_and_dense_grad_step_contract(dev):
         dev.bpr_dense_grad_step(dP, dQ, db, G, None, None, None, 0.01, 0.05, slot=0)     # nothing prepared in slot 0
 
 
-def test_full_size_step_against_float64_index_add(dev):
+def _sum_rows(n_rows, idx_vals):
+    """Float64 sums of value rows by index without atomics (hot items make index_add_ crawl): sort, running
+    sum, differences at the segment ends."""
+    import torch
+    idx = torch.cat([iv[0] for iv in idx_vals])
+    val = torch.cat([iv[1] for iv in idx_vals])
+    order = torch.argsort(idx)
+    idx_s = idx[order]
+    run = val[order].cumsum(0)
+    last = torch.cat([torch.nonzero(idx_s[1:] != idx_s[:-1]).squeeze(1), torch.tensor([idx.shape[0] - 1], device=idx.device)])
+    seg = run[last]
+    seg[1:] = seg[1:] - run[last[:-1]]
+    out = torch.zeros((n_rows,) + tuple(val.shape[1:]), device=val.device, dtype=val.dtype)
+    out[idx_s[last]] = seg
+    return out
+
+
+def test_full_size_step_against_float64_sums(dev):
     """The bench workload at its full size (1M users x 200k items, d=64, 4M triples, Zipf positives): every
     row of P, Q and b after one step against an independent float64 statement of model/BPR.py:36-48 built
-    from torch gathers and index_add_ on the same device, plus two size-independent properties: a step with
+    from torch gathers and sorted segment sums on the same device, plus two size-independent properties: a step with
     lr = 0 leaves every parameter bit for bit, and without regularisation the biases only move mass between
     items (each triple takes s from its negative's bias gradient and gives it to its positive's)."""
     import torch
@@ -314,11 +331,9 @@ def test_full_size_step_against_float64_index_add(dev):
             p, qi, qj = P[ul].double(), Q[il].double(), Q[jl].double()
             z = (p * (qi - qj)).sum(1) + (b[il].double() - b[jl].double()) + 1e-7
             s = torch.sigmoid(-z)
-            gP = torch.zeros(U, d, device=cuda, dtype=torch.float64).index_add_(0, ul, -s[:, None] * (qi - qj) + reg_ * p)
-            gQ = torch.zeros(I, d, device=cuda, dtype=torch.float64)
-            gQ.index_add_(0, il, -s[:, None] * p + reg_ * qi).index_add_(0, jl, s[:, None] * p + reg_ * qj)
-            gb = torch.zeros(I, device=cuda, dtype=torch.float64)
-            gb.index_add_(0, il, -s + reg_ * b[il].double()).index_add_(0, jl, s + reg_ * b[jl].double())
+            gP = _sum_rows(U, [(ul, -s[:, None] * (qi - qj) + reg_ * p)])
+            gQ = _sum_rows(I, [(il, -s[:, None] * p + reg_ * qi), (jl, s[:, None] * p + reg_ * qj)])
+            gb = _sum_rows(I, [(il, -s + reg_ * b[il].double()), (jl, s + reg_ * b[jl].double())])
             return P.double() - lr * gP, Q.double() - lr * gQ, b.double() - lr * gb
 
         P1, Q1, b1 = P.clone(), Q.clone(), b.clone()
@@ -341,4 +356,85 @@ def test_full_size_step_against_float64_index_add(dev):
         d2.synchronize()
         moved = (b3.double() - b.double())
         assert abs(float(moved.sum())) <= 1e-5 * float(moved.abs().sum())
+        d2.close()
+
+
+def test_full_size_apr_step_against_float64_sums(dev):
+    """The APR step (model/APR.py:86-136) at the bench size (1M users x 200k items, d=64, 4M triples) against
+    a float64 statement built from torch gathers and sorted segment sums: deltas, Adagrad accumulators, parameters
+    and the three loss terms.  Property: the bias delta is one vector of norm eps."""
+    import torch
+    from tfrec_amd.device import Device
+    cuda = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=cuda)
+    with torch.cuda.stream(stream):
+        d2 = Device(0, stream=stream.cuda_stream)
+        U, I, d, B = 1_000_000, 200_000, 64, 1 << 22
+        lr, reg, reg_adv, eps = 0.05, 0.01, 1.0, 0.05
+        g = torch.Generator(device=cuda); g.manual_seed(5)
+        P = (torch.rand(U, d, device=cuda, generator=g) - 0.5) * 0.6
+        Q = (torch.rand(I, d, device=cuda, generator=g) - 0.5) * 0.6
+        b = torch.randn(I, device=cuda, generator=g) * 0.1
+        u = torch.randint(0, U, (B,), device=cuda, generator=g, dtype=torch.int32)
+        w = 1.0 / torch.arange(1, I + 1, device=cuda, dtype=torch.float64)
+        cdf = torch.cumsum(w, 0) / w.sum()
+        i = torch.searchsorted(cdf, torch.rand(B, device=cuda, generator=g, dtype=torch.float64)).clamp_(max=I - 1).to(torch.int32)
+        j = torch.randint(0, I, (B,), device=cuda, generator=g, dtype=torch.int32)
+        f64 = torch.float64
+        ul, il, jl = u.long(), i.long(), j.long()
+
+        def clipsig(r):
+            return torch.where((r >= -80.0) & (r <= 1e8), torch.sigmoid(-r), torch.zeros_like(r))
+
+        def softplus_neg(r):
+            return torch.nn.functional.softplus(-r.clamp(-80.0, 1e8))
+
+        def rows(shape, idx_vals):
+            return _sum_rows(shape[0], idx_vals)
+
+        p, qi, qj = P[ul].double(), Q[il].double(), Q[jl].double()
+        bi, bj = b[il].double(), b[jl].double()
+        diff = qi - qj
+        r = (p * diff).sum(1) + (bi - bj)
+        s = clipsig(r)
+        gP = rows((U, d), [(ul, -s[:, None] * diff)])
+        gQ = rows((I, d), [(il, -s[:, None] * p), (jl, s[:, None] * p)])
+        gb = rows((I,), [(il, -s), (jl, s)])
+        dP = eps * gP / gP.pow(2).sum(1, keepdim=True).clamp_min(1e-12).sqrt()
+        dQ = eps * gQ / gQ.pow(2).sum(1, keepdim=True).clamp_min(1e-12).sqrt()
+        db = eps * gb / gb.pow(2).sum().clamp_min(1e-12).sqrt()
+        del gP, gQ
+        pa, diffa = p + dP[ul], (qi + dQ[il]) - (qj + dQ[jl])
+        ra = (pa * diffa).sum(1) + ((bi + db[il]) - (bj + db[jl]))
+        sa = reg_adv * clipsig(ra)
+        creg = 4.0 * reg / (B * d)
+        c = s[:, None] * p + sa[:, None] * pa
+        GP = rows((U, d), [(ul, -s[:, None] * diff - sa[:, None] * diffa + creg * p)])
+        GQ = rows((I, d), [(il, -c + creg * qi), (jl, c + creg * qj)])
+        Gb = rows((I,), [(il, -(s + sa) + creg * d * bi), (jl, (s + sa) + creg * d * bj)])
+        want_loss = torch.stack([softplus_neg(r).sum(), softplus_neg(ra).sum(),
+                                 ((p * p + qi * qi + qj * qj).sum(1) + d * (bi * bi + bj * bj)).sum() / (B * d)])
+        del p, qi, qj, pa, diffa, diff, c
+        want = []
+        for wt, G in ((P, GP), (Q, GQ), (b, Gb)):
+            acc = 0.1 + G * G
+            want.append((wt.double() - lr * G / acc.sqrt(), acc))
+
+        P1, Q1, b1 = P.clone(), Q.clone(), b.clone()
+        acc = [torch.full_like(x, 0.1) for x in (P, Q, b)]
+        dl = [torch.zeros_like(x) for x in (P, Q, b)]
+        loss = torch.zeros(3, device=cuda, dtype=f64)
+        d2.apr_adagrad_step(P1, Q1, b1, *acc, *dl, u, i, j, lr, reg, reg_adv, eps, loss=loss)
+        d2.synchronize()
+
+        def close(got, ref, rtol):
+            err = (got.double() - ref).abs()
+            scale = ref.abs().amax(dim=-1, keepdim=True) if ref.dim() == 2 else ref.abs().max()
+            return bool((err <= 1e-7 + rtol * ref.abs() + rtol * scale).all())
+
+        assert close(dl[0], dP, 1e-4) and close(dl[1], dQ, 1e-4) and close(dl[2], db, 1e-4)
+        for got, got_acc, (ref, ref_acc) in zip((P1, Q1, b1), acc, want):
+            assert close(got, ref, 2e-5) and close(got_acc, ref_acc, 1e-4)
+        assert torch.allclose(loss, want_loss, rtol=1e-5, atol=0.0)
+        assert abs(float(dl[2].double().pow(2).sum().sqrt()) - eps) <= 1e-5 * eps
         d2.close()
