@@ -200,3 +200,54 @@ def test_large_shape_properties(dev):
             assert np.array_equal(ids[r], best)
         assert abs(sc[r, -1] - row[best[-1]]) < 1e-5
         assert not set(ids[r]) & set(indices[indptr[u]:indptr[u + 1]])
+
+
+@pytest.mark.parametrize("mode_name", ["f32", "bf16"])
+def test_full_size_item_table_top100(mode_name):
+    """The item side at its full size (2M items, d=128, k=100, ten masked train items per user): the fused
+    scoring + top-k against a float64 matrix product and torch.topk for 512 users.  f32 scoring: the same
+    ids wherever neighbouring scores are further apart than the float32 rounding of a 128-term dot product;
+    bf16 scoring: the lists overlap the exact ones almost entirely and every reported score is the bf16
+    score of its item.  Both: scores descend, no id twice, no masked id."""
+    import torch
+    from tfrec_amd.device import Device, SCORE_BF16, SCORE_F32
+    cuda = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=cuda)
+    with torch.cuda.stream(stream):
+        d2 = Device(0, stream=stream.cuda_stream)
+        U, I, d, k, n, deg = 100_000, 2_000_000, 128, 100, 512, 10
+        g = torch.Generator(device=cuda); g.manual_seed(17)
+        P = (torch.rand(U, d, device=cuda, generator=g) - 0.5) * 0.4
+        Q = (torch.rand(I, d, device=cuda, generator=g) - 0.5) * 0.4
+        b = torch.randn(I, device=cuda, generator=g) * 0.05
+        users = torch.sort(torch.randperm(U, device=cuda, generator=g)[:n]).values.to(torch.int32)
+        indptr = torch.arange(0, deg * (U + 1), deg, device=cuda, dtype=torch.int64)
+        indices = torch.sort(torch.randint(0, I, (U, deg), device=cuda, generator=g, dtype=torch.int32), dim=1).values.reshape(-1).contiguous()
+        ids = torch.empty(n, k, device=cuda, dtype=torch.int32)
+        sc = torch.empty(n, k, device=cuda)
+        mode = SCORE_F32 if mode_name == "f32" else SCORE_BF16
+        d2.score_topk(P, Q, b, users, k, train=(indptr, indices), mode=mode, out_ids=ids, out_scores=sc)
+        d2.synchronize()
+        Pu = P[users.long()]
+        if mode_name == "bf16":
+            R = Pu.to(torch.bfloat16).double() @ Q.to(torch.bfloat16).double().T + b.double()
+        else:
+            R = Pu.double() @ Q.double().T + b.double()
+        masked = indices.view(U, deg)[users.long()].long()
+        R.scatter_(1, masked, float("-inf"))
+        top = torch.topk(R, k + 1, dim=1)
+        idl = ids.long()
+        assert bool((sc[:, 1:] <= sc[:, :-1]).all())
+        assert bool((torch.sort(idl, dim=1).values.diff(dim=1) > 0).all())
+        assert bool(torch.isfinite(R.gather(1, idl)).all())                     # no masked item reported
+        # every reported score is the (float64-accumulated) score of its item in the mode's operand precision
+        assert torch.allclose(sc.double(), R.gather(1, idl), rtol=0, atol=2e-5)
+        gaps = top.values[:, :-1] - top.values[:, 1:]                           # gap below each of the k best
+        above = torch.cat([torch.full((n, 1), float("inf"), device=cuda, dtype=gaps.dtype), gaps[:, :-1]], dim=1)
+        clear = (gaps > 2e-5) & (above > 2e-5)                                  # positions no rounding can move
+        assert float(clear.float().mean()) > 0.3
+        assert torch.equal(idl[clear], top.indices[:, :k][clear])
+        # rows with near-ties: same sets up to the items whose scores are within rounding of the cut
+        same = (idl.unsqueeze(2) == top.indices[:, :k].unsqueeze(1)).any(2).float().mean()
+        assert float(same) > 0.999
+        d2.close()
