@@ -438,3 +438,39 @@ def test_full_size_apr_step_against_float64_sums(dev):
         assert torch.allclose(loss, want_loss, rtol=1e-5, atol=0.0)
         assert abs(float(dl[2].double().pow(2).sum().sqrt()) - eps) <= 1e-5 * eps
         d2.close()
+
+
+def test_full_size_dns_selection(dev):
+    """Dynamic negative sampling at the large configuration's shape (2M items, d=128, 32 candidates per
+    positive, model/DNSBPR.py:74-79): the chosen candidate is the first best-scored one under a float64
+    scoring of all candidates; where the two best candidates are closer than float32 rounding either may win,
+    but the chosen one always scores within rounding of the best."""
+    import torch
+    from tfrec_amd.device import Device
+    cuda = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=cuda)
+    with torch.cuda.stream(stream):
+        d2 = Device(0, stream=stream.cuda_stream)
+        U, I, d, n, C = 500_000, 2_000_000, 128, 1 << 18, 32
+        g = torch.Generator(device=cuda); g.manual_seed(23)
+        P = (torch.rand(U, d, device=cuda, generator=g) - 0.5) * 0.4
+        Q = (torch.rand(I, d, device=cuda, generator=g) - 0.5) * 0.4
+        b = torch.randn(I, device=cuda, generator=g) * 0.05
+        users = torch.randint(0, U, (n,), device=cuda, generator=g, dtype=torch.int32)
+        cand = torch.randint(0, I, (n, C), device=cuda, generator=g, dtype=torch.int32)
+        cand[:, 5] = cand[:, 2]                                 # a repeated candidate: the first occurrence wins
+        out = torch.empty(n, device=cuda, dtype=torch.int32)
+        d2.dns_select(P, Q, b, users, cand, out=out)
+        d2.synchronize()
+        cl = cand.long()
+        sc = torch.einsum("nd,ncd->nc", P[users.long()].double(), Q[cl].double()) + b[cl].double()
+        best = sc.max(dim=1)
+        chosen_pos = (cl == out.long().unsqueeze(1)).float().argmax(dim=1)       # first slot holding the chosen id
+        assert bool((cl.gather(1, chosen_pos.unsqueeze(1)).squeeze(1) == out.long()).all())     # it is a candidate
+        chosen_score = sc.gather(1, chosen_pos.unsqueeze(1)).squeeze(1)
+        assert bool((best.values - chosen_score <= 2e-5).all())
+        second = sc.clone().scatter_(1, best.indices.unsqueeze(1), float("-inf")).max(dim=1).values
+        clear = best.values - second > 2e-5
+        assert float(clear.float().mean()) > 0.9
+        assert torch.equal(out.long()[clear], cl.gather(1, best.indices.unsqueeze(1)).squeeze(1)[clear])
+        d2.close()
