@@ -571,6 +571,7 @@ __global__ __launch_bounds__(256) void score_topk_kernel(ScoreArgs a)
     };
 
     volatile uint64_t *mysort = sortbuf + wave * CAP;
+    const int lane_row_off = uj * ROWB, lane_bias_off = 4 * h;     // this lane's place in an LDS tile
 
     load_tile(it0);
     store_tile(0);
@@ -586,13 +587,13 @@ __global__ __launch_bounds__(256) void score_topk_kernel(ScoreArgs a)
             f32x16 acc[UW];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 bv = *reinterpret_cast<const float4 *>(bb + sb * 32 + 8 * g + 4 * h);
+                const float4 bv = *reinterpret_cast<const float4 *>(bb + lane_bias_off + sb * 32 + 8 * g);
 #pragma unroll
                 for (int s = 0; s < UW; ++s) {
                     acc[s][4 * g + 0] = bv.x; acc[s][4 * g + 1] = bv.y; acc[s][4 * g + 2] = bv.z; acc[s][4 * g + 3] = bv.w;
                 }
             }
-            const char *arow = qb + (sb * 32 + uj) * ROWB;
+            const char *arow = qb + lane_row_off + sb * (32 * ROWB);
             if constexpr (BF16) {
 #pragma unroll
                 for (int ks = 0; ks < D / 16; ++ks) {
@@ -648,6 +649,8 @@ __global__ __launch_bounds__(256) void score_topk_kernel(ScoreArgs a)
                             }
                         }
                     }
+                } else {
+                    continue;                  // nothing appended: no list grew
                 }
                 TF_PROF_ADD(1, prof_t_ins);
                 // a list that could overflow during the next 32 items is compacted now
