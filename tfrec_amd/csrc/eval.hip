@@ -459,7 +459,7 @@ struct ScoreArgs {
 template <int D, bool BF16, int CAP>
 struct ScoreGeom {
     static constexpr int ESZ = BF16 ? 2 : 4;
-    static constexpr int TI = (D * ESZ >= (BF16 ? 512 : 256)) ? 64 : 128;   // items per step
+    static constexpr int TI = (D * ESZ >= (BF16 ? 128 : 256)) ? 64 : 128;   // items per step
     static constexpr int ROWB = D * ESZ + 16;                // padded LDS row (bank spread)
     static constexpr int CPR = D * ESZ / 16;                 // 16-byte chunks per row
     static constexpr int NLD = TI * CPR / 256;               // chunks per thread per tile
