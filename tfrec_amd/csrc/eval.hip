@@ -335,27 +335,37 @@ __device__ __forceinline__ int wave_select(const uint64_t *list, int cnt, int ve
         // bit taken into the descent is simply found again)
         int bit = differ ? ((31 - __builtin_clz(differ)) | 1) : -1;
         uint32_t hi_cut = __builtin_amdgcn_readfirstlane(all_and) & (bit >= 0 ? ~(uint32_t)((2ull << bit) - 1ull) : 0xffffffffu);
-        bool exact = false;
-        const bool may_stop = kept > k;        // with exactly k held, all bits are resolved: the cut is then the lowest score
+        int exact = 0;
+        const int may_stop = kept > k ? 1 : 0;        // with exactly k held, all bits are resolved: the cut is then the lowest score
         // two bits per round: three counts, then the largest candidate that still has k keys at or above it
 #pragma unroll 1
         for (; bit >= 1; bit -= 2) {
             const uint32_t step = 1u << (bit - 1);
             const uint32_t t1 = hi_cut + step, t2 = hi_cut + 2 * step, t3 = hi_cut + 3 * step;
-            int c1 = 0, c2 = 0, c3 = 0;
+            // all compares first, each into its own mask, then the scalar counts: one shared condition
+            // register would chain every compare to the count before it
+            uint64_t m1[EPL], m2[EPL], m3[EPL];
 #pragma unroll
             for (int q = 0; q < EPL; ++q) {
                 const uint32_t hi = (uint32_t)(keys[q] >> 32);
-                c1 += __popcll(__ballot(hi >= t1));
-                c2 += __popcll(__ballot(hi >= t2));
-                c3 += __popcll(__ballot(hi >= t3));
+                m1[q] = __ballot(hi >= t1);
+                m2[q] = __ballot(hi >= t2);
+                m3[q] = __ballot(hi >= t3);
             }
-            const bool g3 = c3 >= k, g2 = c2 >= k, g1 = c1 >= k;
-            const uint32_t sel = g3 ? 3u : (g2 ? 2u : (g1 ? 1u : 0u));
-            const int cs = g3 ? c3 : (g2 ? c2 : c1);
+            __builtin_amdgcn_sched_barrier(0);
+            int c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+            for (int q = 0; q < EPL; ++q) {
+                c1 += __popcll(m1[q]);
+                c2 += __popcll(m2[q]);
+                c3 += __popcll(m3[q]);
+            }
+            // the counts fall from c1 to c3, so the number of candidates that still have k keys is the choice
+            const uint32_t sel = (uint32_t)(c1 >= k) + (uint32_t)(c2 >= k) + (uint32_t)(c3 >= k);
+            const int cs = sel == 3u ? c3 : (sel == 2u ? c2 : c1);
             hi_cut += sel * step;
-            exact = sel ? cs == k : exact;
-            if (exact && may_stop) break;
+            exact = sel != 0u ? (cs == k ? 1 : 0) : exact;
+            if (exact & may_stop) break;
         }
         cut = (uint64_t)hi_cut << 32;
         if (!exact) {                          // equal scores may straddle the cut: the id decides
