@@ -475,10 +475,11 @@ template <int D, bool BF16, int CAP>
 struct ScoreWave { static constexpr int UW = 1, NW = 4; };
 // NW = waves per workgroup.  All of them share the staged item tile, so eight waves halve the staging work
 // (global loads, LDS writes, barriers) per user.  Measured on MI355X, eight against four waves: bf16 d=128
-// +35 % (2M items, k=100), bf16 d=256 +10 %, bf16 d=64 +7 % on a trained model (-5 % with independent random
-// factors, where one wave's compaction now holds up seven others), f32 d=64 +4 %, f32 d=128 unchanged.
+// +35 % (2M items, k=100), bf16 d=256 +10 %, f32 d=64 +4 %, f32 d=128 unchanged; bf16 d=64, whose kernel needs
+// few enough registers for sixteen waves (one workgroup per CU, 128-item tiles): +22 % on a trained model,
+// +4 to +8 % on synthetic ones.
 template <int CAP>
-struct ScoreWave<64, true, CAP> { static constexpr int UW = 1, NW = 8; };
+struct ScoreWave<64, true, CAP> { static constexpr int UW = 1, NW = 16; };   // 125 registers: sixteen waves fit a CU
 template <int CAP>
 struct ScoreWave<128, true, CAP> { static constexpr int UW = 1, NW = 8; };
 template <int CAP>
@@ -489,7 +490,7 @@ struct ScoreWave<64, false, CAP> { static constexpr int UW = 1, NW = 8; };
 template <int D, bool BF16, int CAP>
 struct ScoreGeom {
     static constexpr int ESZ = BF16 ? 2 : 4;
-    static constexpr int TI = (D * ESZ >= (BF16 ? 128 : 256)) ? 64 : 128;   // items per step
+    static constexpr int TI = D * ESZ >= 256 ? 64 : 128;      // items per step
     static constexpr int ROWB = D * ESZ + 16;                // padded LDS row (bank spread)
     static constexpr int CPR = D * ESZ / 16;                 // 16-byte chunks per row
     static constexpr int NW = ScoreWave<D, BF16, CAP>::NW, NT = 64 * NW;   // waves / threads per workgroup
@@ -981,7 +982,7 @@ static int plan_score(const float *d_Q, int d, int64_t item_lo, int64_t item_hi,
     p->n_items = item_hi - item_lo;
     p->bf16 = score_mode == TFREC_SCORE_BF16;
     p->direct = !p->bf16 && d == p->D && (((uintptr_t)d_Q) & 15u) == 0;
-    p->TI = (p->D * (p->bf16 ? 2 : 4) >= (p->bf16 ? 128 : 256)) ? 64 : 128;      // ScoreGeom::TI
+    p->TI = p->D * (p->bf16 ? 2 : 4) >= 256 ? 64 : 128;      // ScoreGeom::TI
     p->chunk = 1 << 20;          // users per launch: bounds the candidate-list workspace
     const int64_t ub = 128;                        // users per workgroup (ScoreWave::UW = 1 set of 32 per wave)
     const int64_t user_blocks_all = (n + ub - 1) / ub;
