@@ -475,13 +475,13 @@ template <int D, bool BF16, int CAP>
 struct ScoreWave { static constexpr int UW = 1, NW = 4; };
 // NW = waves per workgroup.  All of them share the staged item tile, so eight waves halve the staging work
 // (global loads, LDS writes, barriers) per user.  Measured on MI355X, eight against four waves: bf16 d=128
-// +35 % (2M items, k=100), bf16 d=256 +10 %, f32 d=64 +4 %, f32 d=128 unchanged; bf16 d=64, whose kernel needs
-// few enough registers for sixteen waves (one workgroup per CU, 128-item tiles): +22 % on a trained model,
-// +4 to +8 % on synthetic ones.
+// +35 % (2M items, k=100), bf16 d=256 +10 %, f32 d=64 +4 %, f32 d=128 unchanged.  Sixteen waves (one
+// workgroup per CU) where the kernel fits 128 registers: bf16 d=64 +22 % on a trained model and +4 to +8 % on
+// synthetic ones, bf16 d=128 with lists of 256 a further +4 %; f32 d=64 loses 3 % and stays at eight.
 template <int CAP>
 struct ScoreWave<64, true, CAP> { static constexpr int UW = 1, NW = 16; };   // 125 registers: sixteen waves fit a CU
 template <int CAP>
-struct ScoreWave<128, true, CAP> { static constexpr int UW = 1, NW = 8; };
+struct ScoreWave<128, true, CAP> { static constexpr int UW = 1, NW = CAP <= 256 ? 16 : 8; };
 template <int CAP>
 struct ScoreWave<256, true, CAP> { static constexpr int UW = 1, NW = 8; };
 template <int CAP>
