@@ -490,7 +490,8 @@ struct ScoreWave<64, false, CAP> { static constexpr int UW = 1, NW = 8; };
 template <int D, bool BF16, int CAP>
 struct ScoreGeom {
     static constexpr int ESZ = BF16 ? 2 : 4;
-    static constexpr int TI = D * ESZ >= 256 ? 64 : 128;      // items per step
+    // items per step; a workgroup of sixteen waves is alone on its CU and takes tiles twice as long (half the barriers)
+    static constexpr int TI = (D * ESZ >= 256 ? 64 : 128) * (ScoreWave<D, BF16, CAP>::NW == 16 ? 2 : 1);
     static constexpr int ROWB = D * ESZ + 16;                // padded LDS row (bank spread)
     static constexpr int CPR = D * ESZ / 16;                 // 16-byte chunks per row
     static constexpr int NW = ScoreWave<D, BF16, CAP>::NW, NT = 64 * NW;   // waves / threads per workgroup
@@ -982,7 +983,7 @@ static int plan_score(const float *d_Q, int d, int64_t item_lo, int64_t item_hi,
     p->n_items = item_hi - item_lo;
     p->bf16 = score_mode == TFREC_SCORE_BF16;
     p->direct = !p->bf16 && d == p->D && (((uintptr_t)d_Q) & 15u) == 0;
-    p->TI = p->D * (p->bf16 ? 2 : 4) >= 256 ? 64 : 128;      // ScoreGeom::TI
+    p->TI = 256;      // a multiple of every ScoreGeom::TI
     p->chunk = 1 << 20;          // users per launch: bounds the candidate-list workspace
     const int64_t ub = 128;                        // users per workgroup (ScoreWave::UW = 1 set of 32 per wave)
     const int64_t user_blocks_all = (n + ub - 1) / ub;
