@@ -503,7 +503,7 @@ struct ScoreGeom {
 
 // Developer ablations of the scan loop (never defined in the shipped build): 1 = no list filter,
 // 2 = also no LDS fragment reads, 3 = also no tile staging, 4 = also no final pass, 5 = also no
-// per-tile maximum.
+// per-tile maximum, 6 = 5 with the matrix work issued as 16x16x32 instructions (bf16; a clock comparison).
 #ifndef TF_EVAL_ABLATE
 #define TF_EVAL_ABLATE 0
 #endif
@@ -624,6 +624,17 @@ __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk
 #pragma unroll
                 for (int ks = 0; ks < D / 16; ++ks) {
                     const bf16x8 av = TF_EVAL_ABLATE >= 2 ? pb[0][ks] : *reinterpret_cast<const bf16x8 *>(arow + (16 * ks + 8 * h) * 2);
+#if TF_EVAL_ABLATE >= 6
+                    {   // timing only: the same flops as two 16x16x32 instructions (results meaningless)
+                        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+                        f32x4_t a0 = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]}, a1 = {acc[0][4], acc[0][5], acc[0][6], acc[0][7]};
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pb[0][ks], a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pb[0][ks], a1, 0, 0, 0);
+                        acc[0][0] = a0[0]; acc[0][1] = a0[1]; acc[0][2] = a0[2]; acc[0][3] = a0[3];
+                        acc[0][4] = a1[0]; acc[0][5] = a1[1]; acc[0][6] = a1[2]; acc[0][7] = a1[3];
+                        continue;
+                    }
+#endif
 #pragma unroll
                     for (int s = 0; s < UW; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, pb[s][ks], acc[s], 0, 0, 0);
                 }
