@@ -701,9 +701,17 @@ __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk
                     uint64_t *sl = a.lists + ((size_t)blockIdx.y * a.n + sur) * CAP;
                     const int64_t slo = __shfl(mlo[s], src, 64), shi = __shfl(mhi[s], src, 64);
                     float nt;
+                    // A user with few masked (train) items is not checked against them during the scan: at most
+                    // L of the held entries can be masked, so the best k + L unchecked ones contain the best k
+                    // valid ones and their lowest score bounds the k-th valid score from below.  The final pass
+                    // checks whatever is left.  (Saves the row fetch and the membership tests of every
+                    // mid-scan compaction; the threshold is a few ranks looser.)
+                    const int64_t L = shi - slo;
+                    const bool defer = a.train_indices != nullptr && a.k + L <= CAP / 2;
                     const int nc = wave_select<CAP>(sl, __builtin_amdgcn_readlane(mycnt[s], src), __builtin_amdgcn_readlane(myver[s], src),
-                                                    a.k, a.train_indices, slo, shi, mysort, lane, &nt, sl, prof_acc);
-                    if (uj == src) { mycnt[s] = nc; myver[s] = nc; th[s] = nt; }
+                                                    defer ? a.k + (int)L : a.k, defer ? nullptr : a.train_indices, slo, shi, mysort, lane,
+                                                    &nt, sl, prof_acc);
+                    if (uj == src) { mycnt[s] = nc; myver[s] = defer ? 0 : nc; th[s] = nt; }
                 }
                 TF_PROF_ADD(2, prof_t_cmp);
             }
