@@ -251,3 +251,35 @@ def test_full_size_item_table_top100(mode_name):
         same = (idl.unsqueeze(2) == top.indices[:, :k].unsqueeze(1)).any(2).float().mean()
         assert float(same) > 0.999
         d2.close()
+
+
+@pytest.mark.parametrize("k,deg", [(50, 20), (100, 24), (100, 40), (10, 100)])
+def test_masked_items_at_the_top_of_every_ranking(dev, k, deg):
+    """Train items that would fill the top of the list (their biases tower over everything else): whether the
+    scan checks them at every compaction (long rows) or only in the final pass (short rows, k + row length
+    survivors kept meanwhile), the result is the exact top-k of the unmasked items."""
+    rng = np.random.default_rng(k * 1000 + deg)
+    U, I, d = 700, 30000, 64
+    P = rng.uniform(-0.3, 0.3, (U, d)).astype(np.float32)
+    Q = rng.uniform(-0.3, 0.3, (I, d)).astype(np.float32)
+    b = rng.normal(0, 0.05, I).astype(np.float32)
+    hot = rng.choice(I, 3 * deg, replace=False)
+    b[hot] += 10.0
+    rows = np.stack([np.sort(rng.choice(hot, deg, replace=False)) for _ in range(U)]).astype(np.int32)
+    indptr = np.arange(0, deg * (U + 1), deg, dtype=np.int64)
+    users = np.arange(U, dtype=np.int32)
+    ids, sc = dev.score_topk(dev.array(P), dev.array(Q), dev.array(b), dev.array(users), k, train=dcsr(dev, indptr, rows.ravel()))
+    ids, sc = ids.numpy(), sc.numpy()
+    R = P.astype(np.float64) @ Q.T.astype(np.float64) + b
+    np.put_along_axis(R, rows.astype(np.int64), -np.inf, axis=1)
+    best = np.argsort(-R, axis=1, kind="stable")[:, :k]
+    want = np.take_along_axis(R, best, axis=1)
+    assert np.abs(sc - want).max() < 1e-4
+    top1 = np.take_along_axis(R, np.argsort(-R, axis=1, kind="stable")[:, :k + 1], axis=1)
+    below = -np.diff(top1, axis=1)                                          # gap under each of the k best
+    above = np.concatenate([np.full((U, 1), np.inf), below[:, :-1]], axis=1)
+    clear = (below > 1e-5) & (above > 1e-5)                                  # positions no float32 rounding can move
+    assert clear.mean() > 0.5
+    assert np.array_equal(ids[clear], best[clear])
+    for u in range(0, U, 50):
+        assert not set(ids[u]) & set(rows[u])
