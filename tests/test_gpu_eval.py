@@ -283,3 +283,47 @@ def test_masked_items_at_the_top_of_every_ranking(dev, k, deg):
     assert np.array_equal(ids[clear], best[clear])
     for u in range(0, U, 50):
         assert not set(ids[u]) & set(rows[u])
+
+
+@pytest.mark.parametrize("mode_name", ["f32", "bf16"])
+@pytest.mark.parametrize("d", [8, 20, 32, 48, 64, 100, 128, 200, 256])
+@pytest.mark.parametrize("k", [1, 50, 113, 240])
+def test_every_kernel_instantiation(dev, mode_name, d, k):
+    """Every (padded factor size, list capacity, score mode) instantiation of the scoring kernel -- they differ in
+    waves per workgroup, tile length and registers -- on a user count that leaves waves and workgroups partly
+    filled, with masked rows of mixed length, against a float64 product in the mode's operand precision."""
+    import torch
+    from tfrec_amd.device import SCORE_BF16, SCORE_F32
+    if mode_name == "f32" and d > 128:
+        with pytest.raises(Exception):
+            dev.score_topk(dev.zeros((4, d), np.float32), dev.zeros((9, d), np.float32), dev.zeros(9, np.float32),
+                           dev.array(np.arange(4, dtype=np.int32)), 1, mode=SCORE_F32)
+        return
+    rng = np.random.default_rng(d * 1000 + k)
+    U, I, n = 900, 7001, 837
+    P = rng.uniform(-0.5, 0.5, (U, d)).astype(np.float32)
+    Q = rng.uniform(-0.5, 0.5, (I, d)).astype(np.float32)
+    b = rng.normal(0, 0.1, I).astype(np.float32)
+    users = np.sort(rng.choice(U, n, replace=False)).astype(np.int32)
+    lens = rng.choice([0, 3, 20, 150, 700], U)
+    indptr = np.zeros(U + 1, np.int64); indptr[1:] = np.cumsum(lens)
+    indices = np.concatenate([np.sort(rng.choice(I, m, replace=False)) for m in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
+    mode = SCORE_F32 if mode_name == "f32" else SCORE_BF16
+    ids, sc = dev.score_topk(dev.array(P), dev.array(Q), dev.array(b), dev.array(users), k, train=dcsr(dev, indptr, indices), mode=mode)
+    ids, sc = ids.numpy(), sc.numpy()
+    if mode_name == "bf16":
+        rnd = lambda x: torch.from_numpy(x).to(torch.bfloat16).double().numpy()
+    else:
+        rnd = lambda x: x.astype(np.float64)
+    R = rnd(P[users]) @ rnd(Q).T + b
+    for r, u in enumerate(users):
+        R[r, indices[indptr[u]:indptr[u + 1]]] = -np.inf
+    order = np.argsort(-R, axis=1, kind="stable")[:, :k + 1]
+    top = np.take_along_axis(R, order, axis=1)
+    assert np.abs(sc - top[:, :k]).max() < 2e-5
+    below = top[:, :k] - top[:, 1:]
+    above = np.concatenate([np.full((n, 1), np.inf), below[:, :-1]], axis=1)
+    clear = (below > 2e-5) & (above > 2e-5)
+    assert clear.mean() > 0.5
+    assert np.array_equal(ids[clear], order[:, :k][clear])
+    assert (np.diff(sc, axis=1) <= 0).all()
