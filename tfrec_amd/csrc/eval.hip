@@ -1004,15 +1004,19 @@ static int plan_score(const float *d_Q, int d, int64_t item_lo, int64_t item_hi,
     p->direct = !p->bf16 && d == p->D && (((uintptr_t)d_Q) & 15u) == 0;
     p->TI = 256;      // a multiple of every ScoreGeom::TI
     p->chunk = 1 << 20;          // users per launch: bounds the candidate-list workspace
-    const int64_t ub = 128;                        // users per workgroup (ScoreWave::UW = 1 set of 32 per wave)
+    // waves per workgroup of the instantiation that will run (ScoreWave<D, BF16, CAP>::NW)
+    const int nw = p->bf16 ? (p->D == 64 ? 16 : (p->D == 128 ? (p->CAP <= 256 ? 16 : 8) : (p->D == 256 ? 8 : 4))) : (p->D == 64 ? 8 : 4);
+    const int64_t ub = 32 * nw;                    // users per workgroup
     const int64_t user_blocks_all = (n + ub - 1) / ub;
+    const int64_t want_blocks = 512 * 4 / nw > 256 ? 512 * 4 / nw : 256;     // 2048 waves, and no CU left without a workgroup
     int splits = 1;
-    if (user_blocks_all < 512 && p->n_items > 0) {
+    if (user_blocks_all < want_blocks && p->n_items > 0) {
         // few users: also split the item range over workgroups, then merge the partial lists
-        const int64_t want = (512 + user_blocks_all - 1) / user_blocks_all;
+        const int64_t want = (want_blocks + user_blocks_all - 1) / user_blocks_all;
         const int64_t maxs = (p->n_items + 4095) / 4096;
         splits = (int)(want < maxs ? want : maxs);
         if (splits < 1) splits = 1;
+        if (splits > 16) splits = 16;              // beyond that the merge of the partial lists costs more than the scan gains
         if ((int64_t)splits * k > 2048) splits = 2048 / k;
     }
     p->split_items = p->n_items > 0 ? ((p->n_items + splits - 1) / splits + p->TI - 1) / p->TI * p->TI : p->TI;
