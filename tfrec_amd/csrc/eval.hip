@@ -340,6 +340,9 @@ __device__ __forceinline__ int wave_select(const uint64_t *list, int cnt, int ve
         // two bits per round: three counts, then the largest candidate that still has k keys at or above it
 #pragma unroll 1
         for (; bit >= 1; bit -= 2) {
+#ifdef TF_EVAL_PROFILE
+            if (prof_acc) prof_acc[13] += 1;
+#endif
             const uint32_t step = 1u << (bit - 1);
             const uint32_t t1 = hi_cut + step, t2 = hi_cut + 2 * step, t3 = hi_cut + 3 * step;
             // all compares first, each into its own mask, then the scalar counts: one shared condition
@@ -369,6 +372,9 @@ __device__ __forceinline__ int wave_select(const uint64_t *list, int cnt, int ve
         }
         cut = (uint64_t)hi_cut << 32;
         if (!exact) {                          // equal scores may straddle the cut: the id decides
+#ifdef TF_EVAL_PROFILE
+            if (prof_acc) prof_acc[14] += 1;
+#endif
 #pragma unroll 1
             for (int bit = 31; bit >= 0; --bit) {
                 const uint64_t t2 = cut | (1ull << bit);
