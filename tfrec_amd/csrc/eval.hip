@@ -416,14 +416,18 @@ __device__ __forceinline__ int wave_finish(const uint64_t *__restrict__ list, in
 {
     constexpr int SN = CAP / 2;               // k <= CAP/2 - 16 for every capacity in use
     float tau;
-    const int nc = wave_select<CAP>(list, cnt, ver, k, mask_idx, mlo, mhi, sortbuf, lane, &tau, sortbuf);
+    // a list that fits the sort as it is needs no selection first (asking for more survivors than it can
+    // hold makes the selection keep every unmasked entry); the sort then puts the best k in front
+    const bool small = cnt <= SN;
+    const int held = wave_select<CAP>(list, cnt, ver, small ? CAP : k, mask_idx, mlo, mhi, sortbuf, lane, &tau, sortbuf);
+    const int nc = held < k ? held : k;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     uint64_t keys[SN / 64];
 #pragma unroll
     for (int q = 0; q < SN / 64; ++q) {
         const int e = lane + 64 * q;
-        keys[q] = e < nc ? sortbuf[e] : 0;
+        keys[q] = e < held ? sortbuf[e] : 0;
     }
     bitonic_sort<SN, SN>(keys, lane);
 #pragma unroll
