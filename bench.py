@@ -20,6 +20,8 @@ user sample) and "other_paths" (APR step, DNS selection and the device epoch pip
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -129,8 +131,47 @@ def other_paths(dev, P, Q, b, U, I, d, B, gen, cuda, steps=10):
     return out
 
 
+def eval_block(dev, cuda, n, I, d, k, deg, tdeg, label):
+    """Full-rank evaluation (model/BPR.py:76-80 + evaluator/evaluator.py:29-32) of n users against I items on
+    freshly initialised tables (model/base/MatrixFactorization.py:17-21: factors ~ U(-0.05, 0.05)), so that no two
+    users share a ranking.  Two bias settings: "independent" (b = 0, rankings unrelated between users: the worst
+    case for the per-wave top-k filter) and "popularity_biased" (b ~ N(0, 3 x the spread of a factor dot product):
+    the users of a wave prefer the same items, as after training).  users/s and the MFMA roofline of each."""
+    from tfrec_amd.device import SCORE_F32, SCORE_BF16
+    g = torch.Generator(device=cuda)
+    g.manual_seed(777)
+    P = (torch.rand(n, d, device=cuda, generator=g) - 0.5) * 0.1
+    Q = (torch.rand(I, d, device=cuda, generator=g) - 0.5) * 0.1
+    dot_std = (d ** 0.5) * (0.05 ** 2 / 3.0)
+    eu = torch.arange(n, device=cuda, dtype=torch.int32)
+    indptr = torch.arange(0, deg * (n + 1), deg, device=cuda, dtype=torch.int64)
+    indices = torch.sort(torch.randint(0, I, (n, deg), device=cuda, generator=g, dtype=torch.int32), dim=1).values.reshape(-1).contiguous()
+    tptr = torch.arange(0, tdeg * (n + 1), tdeg, device=cuda, dtype=torch.int64)
+    tidx = torch.sort(torch.randint(0, I, (n, tdeg), device=cuda, generator=g, dtype=torch.int32), dim=1).values.reshape(-1).contiguous()
+    res = {"shape": "%s: %d users x %d items, d=%d, k=%d, %d train + %d test items per user" % (label, n, I, d, k, deg, tdeg)}
+    for case, sigma in (("independent", 0.0), ("popularity_biased", 3.0 * dot_std)):
+        b = torch.randn(I, device=cuda, generator=g) * sigma
+        ev = {}
+        for mode, name in ((SCORE_F32, "f32"), (SCORE_BF16, "bf16")):
+            dev.eval_fullrank(P, Q, b, eu, (indptr, indices), (tptr, tidx), k, mode=mode)      # warm-up, sizes the workspace
+            torch.cuda.synchronize()
+            reps = 3 if name == "bf16" else 1
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                dev.eval_fullrank(P, Q, b, eu, (indptr, indices), (tptr, tidx), k, mode=mode)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / reps
+            tf = 2.0 * I * d * n / dt / 1e12
+            ev[name] = {"users_per_s": n / dt, "ms": dt * 1e3,
+                        "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS[name], "unit": "TFLOP/s",
+                                     "frac": tf / MFMA_PEAK_TFLOPS[name], "traffic": None}}
+        res[case] = ev
+    return res
+
+
 def cpu_baseline(U, I, d, B, lr, reg, budget_s=12.0):
-    """The CPU oracle (plain C, one thread) on the same table shapes and batch distribution."""
+    """The CPU oracle (plain C, OpenMP over row owners) on the same table shapes and batch distribution, on the
+    host cores this process may use (the box sets OMP_NUM_THREADS to its share)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
     rng = np.random.default_rng(2018)
@@ -141,19 +182,31 @@ def cpu_baseline(U, I, d, B, lr, reg, budget_s=12.0):
     cdf = np.cumsum(w) / w.sum()
     perm = rng.permutation(I)
     ws = orc.Workspace(U, I, d)
+    cores = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), os.cpu_count() or 1, 64))
+
+    def draw():
+        return (rng.integers(0, U, B).astype(np.int32), perm[np.searchsorted(cdf, rng.random(B)).clip(max=I - 1)].astype(np.int32),
+                rng.integers(0, I, B).astype(np.int32))
+    for _ in range(2):          # untimed: first touch of the accumulators, thread pool start
+        orc.bpr_step(P, Q, b, *draw(), lr, reg, ws=ws, threads=cores)
     done, t_used, steps = 0, 0.0, 0
     while t_used < budget_s:
-        users = rng.integers(0, U, B).astype(np.int32)
-        pos = perm[np.searchsorted(cdf, rng.random(B)).clip(max=I - 1)].astype(np.int32)
-        neg = rng.integers(0, I, B).astype(np.int32)
+        users, pos, neg = draw()
         t0 = time.perf_counter()
-        orc.bpr_step(P, Q, b, users, pos, neg, lr, reg, ws=ws)
+        orc.bpr_step(P, Q, b, users, pos, neg, lr, reg, ws=ws, threads=cores)
         t_used += time.perf_counter() - t0
         done += B
         steps += 1
-    return {"value": done / t_used, "unit": "triples/s", "cores": 1, "kind": "port",
-            "sample": "%d steps of %d triples on the same %dx%d d=%d tables (oracle/mf_oracle.c, scalar C, step math only)"
-                      % (steps, B, U, I, d)}
+    one, t1 = 0, 0.0
+    while t1 < 3.0:
+        users, pos, neg = draw()
+        t0 = time.perf_counter()
+        orc.bpr_step(P, Q, b, users, pos, neg, lr, reg, ws=ws)
+        t1 += time.perf_counter() - t0
+        one += B
+    return {"value": done / t_used, "unit": "triples/s", "cores": cores, "kind": "port", "one_core_value": one / t1,
+            "sample": "%d steps of %d triples on the same %dx%d d=%d tables (oracle/mf_oracle.c, C with OpenMP over row owners, "
+                      "step math only; no TensorFlow number exists)" % (steps, B, U, I, d)}
 
 
 def cpu_baseline_eval(I, d, k, n_users=1024, threads=16):
@@ -192,11 +245,33 @@ def cpu_baseline_eval(I, d, k, n_users=1024, threads=16):
             "sample": "%d users x %d items, d=%d, k=%d (oracle/mf_oracle.c, scalar C)" % (n_users, I, d, k)}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script as child processes (one per
+    GPU, the environment torch.distributed.run would give them) and pass rank 0's JSON line through.  The
+    parent never touches the GPU and replaces no process image."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, WORLD_SIZE=str(n), RANK=str(r), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return next((c for c in codes if c), 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1 << 22, help="triples per step per GPU")
     ap.add_argument("--users", type=int, default=1_000_000)
     ap.add_argument("--items", type=int, default=200_000)
@@ -206,6 +281,7 @@ def main():
     ap.add_argument("--topk", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
+    ap.add_argument("--no-c5", action="store_true", help="skip the evaluation block at the 2M-item, d=128, k=100 shape")
     ap.add_argument("--no-other", action="store_true", help="skip the APR step and DNS selection timings")
     ap.add_argument("--prep-batches", type=int, default=1, help="batches sorted per index preparation (single GPU)")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU code path even on one GPU (testing)")
@@ -216,13 +292,15 @@ def main():
     ap.add_argument("--extras", action="store_true", help="also time the reference batch size (512 triples per step)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))          # before anything initialises the GPU in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -371,9 +449,11 @@ def main():
                 indices = torch.sort(torch.randint(0, I, (U, deg), device=cuda, generator=g2, dtype=torch.int32), dim=1).values.reshape(-1).contiguous()
                 tptr = torch.arange(0, tdeg * (U + 1), tdeg, device=cuda, dtype=torch.int64)
                 tidx = torch.sort(torch.randint(0, I, (U, tdeg), device=cuda, generator=g2, dtype=torch.int32), dim=1).values.reshape(-1).contiguous()
-                ev = {}
+                # freshly initialised tables of the same layout (the trained ones rank every user alike)
+                fresh = ShardedBprTrainer(dev, U, I, d, lr, reg, seed=4242, device=cuda, item_mode=trainer.item_mode)
+                ev = {"model": "fresh tables, factors ~ U(-0.05, 0.05), b = 0 (independent rankings)"}
                 for mode, name in ((SCORE_F32, "f32"), (SCORE_BF16, "bf16")):
-                    se = ShardedEvaluator(dev, trainer, (indptr, indices), (tptr, tidx), eu, top_k=k, mode=mode)
+                    se = ShardedEvaluator(dev, fresh, (indptr, indices), (tptr, tidx), eu, top_k=k, mode=mode)
                     se.evaluate()                                      # warm-up, sizes the workspaces
                     barrier()
                     t1 = time.perf_counter()
@@ -435,6 +515,8 @@ def main():
             out["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(B, d),
+                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
+                                  "committed with the profiles), not measured in this run",
                 "kernel": "one BPR step = build_keys + radix sort + seg_tile/seg_fixup (user side) + seg_tile/seg_fixup (item side)",
                 "algorithmic_bytes_per_triple": alg_bytes_per_triple,
                 "device_ms_per_step": dev_ms / args.steps,
@@ -458,33 +540,21 @@ def main():
                                               "us_per_step": e2.elapsed_time(e3) * 1e3 / 200}
 
             if not args.no_eval:
-                n = min(args.eval_users, U)
-                k = args.topk
-                eu = torch.arange(n, device=cuda, dtype=torch.int32)
-                deg = 20
-                indptr = torch.arange(0, deg * (U + 1), deg, device=cuda, dtype=torch.int64)
-                indices = torch.sort(torch.randint(0, I, (U, deg), device=cuda, generator=gen, dtype=torch.int32), dim=1).values.reshape(-1).contiguous()
-                tdeg = 3
-                tptr = torch.arange(0, tdeg * (U + 1), tdeg, device=cuda, dtype=torch.int64)
-                tidx = torch.sort(torch.randint(0, I, (U, tdeg), device=cuda, generator=gen, dtype=torch.int32), dim=1).values.reshape(-1).contiguous()
-                ev = {}
-                for mode, name in ((SCORE_F32, "f32"), (SCORE_BF16, "bf16")):
-                    dev.eval_fullrank(P, Q, b, eu, (indptr, indices), (tptr, tidx), k, mode=mode)      # warm-up, sizes the workspace
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    dev.eval_fullrank(P, Q, b, eu, (indptr, indices), (tptr, tidx), k, mode=mode)
-                    torch.cuda.synchronize()
-                    dt = time.perf_counter() - t1
-                    tf = 2.0 * I * d * n / dt / 1e12
-                    ev[name] = {"users_per_s": n / dt, "ms": dt * 1e3, "users": n, "items": I, "topk": k,
-                                "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS[name], "unit": "TFLOP/s",
-                                             "frac": tf / MFMA_PEAK_TFLOPS[name]}}
+                # the trained tables are not evaluated: 400 summed-gradient steps at this batch size leave item
+                # biases that make every user's ranking the same, the easiest case for the top-k filter
+                ev = eval_block(dev, cuda, min(args.eval_users, U), I, d, args.topk, 20, 3, "C2 shape")
+                if not args.no_c5:
+                    c5 = eval_block(dev, cuda, args.eval_users, 2_000_000, 128, 100, 10, 3, "C5 shape")
+                    ev["c5"] = c5
+                    ev["roofline"] = dict(c5["independent"]["bf16"]["roofline"],
+                                          kernel="score_topk_kernel (bf16 MFMA 32x32x16) + metrics, whole call",
+                                          workload="%d users x 2M items, d=128, k=100, independent factors" % args.eval_users)
                 out["eval"] = ev
             if not args.no_other:
                 out["other_paths"] = other_paths(dev, P, Q, b, U, I, d, B, gen, cuda)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(U, I, d, 1 << 17, lr, reg)
-                if "eval" in out:
+                if "eval" in out and "error" not in out["eval"]:
                     out["eval"]["cpu_baseline"] = cpu_baseline_eval(I, d, args.topk)
         if rank == 0:
             print(json.dumps(out), flush=True)

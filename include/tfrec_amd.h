@@ -117,8 +117,8 @@ int tfrec_sample_negatives(tfrec_ctx *ctx, const int64_t *d_indptr, const int32_
                            int64_t U, int64_t I, int64_t nnz, int n_neg, uint64_t seed, uint64_t stream,
                            int64_t first_interaction,
                            int32_t *d_users_out, int32_t *d_pos_out, int32_t *d_neg_out);
-/* A permutation of 0..n-1 that is a pure function of (seed, stream, n): stable sort of 32-bit hash
- * keys (the shuffle of data/dataiterator.py:52-54). */
+/* A permutation of 0..n-1 that is a pure function of (seed, stream, n): stable sort by 64-bit hash
+ * keys, as two 32-bit sorts (the shuffle of data/dataiterator.py:52-54). */
 int tfrec_shuffle_perm(tfrec_ctx *ctx, int64_t n, uint64_t seed, uint64_t stream, int32_t *d_perm_out);
 /* dst[r, :] = src[perm[r], :] for rows of `width` int32 (applies a shuffle to index arrays). */
 int tfrec_gather_rows_i32(tfrec_ctx *ctx, const int32_t *d_src, int64_t n_src, const int32_t *d_perm,

@@ -38,7 +38,8 @@ def build_oracle(force=False):
     if not force and _newer(out, src):
         return out
     # -ffp-contract=off: every rounding in the restatement is the one written in the source
-    cmd = ["gcc", "-O2", "-std=c11", "-ffp-contract=off", "-fPIC", "-shared", src, "-o", out, "-lm"]
+    # -fopenmp: only oracle_bpr_step_mt (the multi-core CPU baseline of the benchmark) has parallel regions
+    cmd = ["gcc", "-O2", "-std=c11", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared", src, "-o", out, "-lm"]
     subprocess.check_call(cmd)
     return out
 

@@ -23,6 +23,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 /* ------------------------------------------------------------------------- */
 /* workspace: dense double accumulators, cleared only where touched           */
@@ -145,6 +148,89 @@ int oracle_bpr_step(oracle_ws *w, float *P, float *Q, float *b,
         b[i] = (float)((double)b[i] - lr * w->gb[i]);
     }
     ws_clear(w);
+    if (loss_out) { loss_out[0] = rank_loss; loss_out[1] = reg_loss; }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* The same step on several host threads (OpenMP), for the CPU baseline of    */
+/* the benchmark.  Thread T owns the rows whose id is T modulo the thread     */
+/* count and adds their gradient terms in batch order, so every parameter     */
+/* comes out bit for bit as oracle_bpr_step leaves it; only the two loss sums */
+/* are added in a different order.  s_buf: B doubles of scratch.              */
+/* ------------------------------------------------------------------------- */
+int oracle_bpr_step_mt(oracle_ws *w, float *P, float *Q, float *b,
+                       const int32_t *users, const int32_t *pos, const int32_t *neg, int64_t B,
+                       double lr, double reg, double *loss_out, double *s_buf, int nthreads)
+{
+    const int d = w->d;
+    if (nthreads < 1) nthreads = 1;
+    for (int64_t t = 0; t < B; ++t) {
+        const int32_t u = users[t], i = pos[t], j = neg[t];
+        if (u < 0 || u >= w->U || i < 0 || i >= w->I || j < 0 || j >= w->I) return -1;
+    }
+    double rank_loss = 0, reg_loss = 0;
+#pragma omp parallel for num_threads(nthreads) schedule(static) reduction(+ : rank_loss, reg_loss)
+    for (int64_t t = 0; t < B; ++t) {
+        const int32_t u = users[t], i = pos[t], j = neg[t];
+        const float *p = P + (size_t)u * d, *qi = Q + (size_t)i * d, *qj = Q + (size_t)j * d;
+        const double z = ((dot_rows(p, qi, d) + (double)b[i]) - (dot_rows(p, qj, d) + (double)b[j])) + 1e-7;
+        rank_loss += softplus(-z);
+        s_buf[t] = sigmoid(-z);
+        double r = 0;
+        for (int f = 0; f < d; ++f) r += 0.5 * ((double)p[f] * p[f] + (double)qi[f] * qi[f] + (double)qj[f] * qj[f]);
+        reg_loss += r + 0.5 * ((double)b[i] * b[i] + (double)b[j] * b[j]);
+    }
+#pragma omp parallel num_threads(nthreads)
+    {
+        int T = 0, NT = 1;
+#ifdef _OPENMP
+        T = omp_get_thread_num(); NT = omp_get_num_threads();
+#endif
+        /* gradient sums of the rows this thread owns, all at the pre-step parameters */
+        for (int64_t t = 0; t < B; ++t) {
+            const int32_t u = users[t], i = pos[t], j = neg[t];
+            const double s = s_buf[t];
+            const float *p = P + (size_t)u * d, *qi = Q + (size_t)i * d, *qj = Q + (size_t)j * d;
+            if (u % NT == T) {
+                double *gp = w->gP + (size_t)u * d;
+                for (int f = 0; f < d; ++f) gp[f] += -s * ((double)qi[f] - (double)qj[f]) + reg * (double)p[f];
+                w->cntU[u]++;
+            }
+            if (i % NT == T) {
+                double *g = w->gQ + (size_t)i * d;
+                for (int f = 0; f < d; ++f) g[f] += -s * (double)p[f] + reg * (double)qi[f];
+                w->gb[i] += -s + reg * (double)b[i];
+                w->cntI[i]++;
+            }
+            if (j % NT == T) {
+                double *g = w->gQ + (size_t)j * d;
+                for (int f = 0; f < d; ++f) g[f] += s * (double)p[f] + reg * (double)qj[f];
+                w->gb[j] += s + reg * (double)b[j];
+                w->cntI[j]++;
+            }
+        }
+#pragma omp barrier
+        /* apply once per distinct row (the first occurrence met applies and clears) */
+        for (int64_t t = 0; t < B; ++t) {
+            const int32_t u = users[t];
+            if (u % NT == T && w->cntU[u]) {
+                float *p = P + (size_t)u * d; double *g = w->gP + (size_t)u * d;
+                for (int f = 0; f < d; ++f) { p[f] = (float)((double)p[f] - lr * g[f]); g[f] = 0.0; }
+                w->cntU[u] = 0;
+            }
+            for (int side = 0; side < 2; ++side) {
+                const int32_t i = side ? neg[t] : pos[t];
+                if (i % NT == T && w->cntI[i]) {
+                    float *q = Q + (size_t)i * d; double *g = w->gQ + (size_t)i * d;
+                    for (int f = 0; f < d; ++f) { q[f] = (float)((double)q[f] - lr * g[f]); g[f] = 0.0; }
+                    b[i] = (float)((double)b[i] - lr * w->gb[i]);
+                    w->gb[i] = 0.0;
+                    w->cntI[i] = 0;
+                }
+            }
+        }
+    }
     if (loss_out) { loss_out[0] = rank_loss; loss_out[1] = reg_loss; }
     return 0;
 }
@@ -497,7 +583,7 @@ int64_t oracle_sample_negatives(const int64_t *indptr, const int32_t *indices, i
     }
     return n_full;
 }
-void oracle_shuffle_keys(int64_t n, uint64_t seed, uint64_t stream, uint32_t *keys_out)
+void oracle_shuffle_keys(int64_t n, uint64_t seed, uint64_t stream, uint64_t *keys_out)
 {
-    for (int64_t t = 0; t < n; ++t) keys_out[t] = (uint32_t)(o_draw64(seed, stream ^ 0x73687566666c65ull, (uint64_t)t, 0) >> 32);
+    for (int64_t t = 0; t < n; ++t) keys_out[t] = o_draw64(seed, stream ^ 0x73687566666c65ull, (uint64_t)t, 0);
 }

@@ -44,6 +44,9 @@ def lib():
         L.oracle_bpr_step.restype = C.c_int
         L.oracle_bpr_step.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _i32p, _i32p, _i32p, C.c_int64,
                                       C.c_double, C.c_double, _f64p]
+        L.oracle_bpr_step_mt.restype = C.c_int
+        L.oracle_bpr_step_mt.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _i32p, _i32p, _i32p, C.c_int64,
+                                         C.c_double, C.c_double, _f64p, _f64p, C.c_int]
         L.oracle_apr_step.restype = C.c_int
         L.oracle_apr_step.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p,
                                       C.c_void_p, C.c_void_p, C.c_void_p,
@@ -81,12 +84,17 @@ class Workspace:
             self.h = None
 
 
-def bpr_step(P, Q, b, users, pos, neg, lr, reg, ws=None):
-    """In-place BPR-SGD minibatch step on float32 arrays; returns (rank_loss, reg_loss)."""
+def bpr_step(P, Q, b, users, pos, neg, lr, reg, ws=None, threads=1):
+    """In-place BPR-SGD minibatch step on float32 arrays; returns (rank_loss, reg_loss).
+    ``threads`` > 1 runs the multi-threaded statement of the same step (parameters bit-identical)."""
     ws = ws or Workspace(P.shape[0], Q.shape[0], P.shape[1])
     out = np.zeros(2)
-    rc = lib().oracle_bpr_step(ws.h, P, Q, b, _c(users, np.int32), _c(pos, np.int32), _c(neg, np.int32),
-                               len(users), float(lr), float(reg), out)
+    if threads > 1:
+        rc = lib().oracle_bpr_step_mt(ws.h, P, Q, b, _c(users, np.int32), _c(pos, np.int32), _c(neg, np.int32),
+                                      len(users), float(lr), float(reg), out, np.empty(len(users)), int(threads))
+    else:
+        rc = lib().oracle_bpr_step(ws.h, P, Q, b, _c(users, np.int32), _c(pos, np.int32), _c(neg, np.int32),
+                                   len(users), float(lr), float(reg), out)
     if rc:
         raise IndexError("index out of range in oracle_bpr_step")
     return float(out[0]), float(out[1])
@@ -198,11 +206,11 @@ def sample_negatives(indptr, indices, n_users, n_items, n_neg, seed, stream, fir
 
 
 def shuffle_perm(n, seed, stream):
-    """CPU statement of tfrec_shuffle_perm: stable argsort of the 32-bit hash keys."""
+    """CPU statement of tfrec_shuffle_perm: stable argsort of the 64-bit hash keys."""
     L = lib()
     L.oracle_shuffle_keys.restype = None
-    L.oracle_shuffle_keys.argtypes = [C.c_int64, C.c_uint64, C.c_uint64, np.ctypeslib.ndpointer(np.uint32, flags="C")]
-    keys = np.empty(n, np.uint32)
+    L.oracle_shuffle_keys.argtypes = [C.c_int64, C.c_uint64, C.c_uint64, np.ctypeslib.ndpointer(np.uint64, flags="C")]
+    keys = np.empty(n, np.uint64)
     L.oracle_shuffle_keys(n, seed, stream, keys)
     return np.argsort(keys, kind="stable").astype(np.int32)
 

@@ -21,9 +21,14 @@ def test_single_rank_sharded_path_matches_unsharded(oracle, item_mode):
     for u, i, j in batches:
         tr.step(u, i, j)
     if item_mode == "dense":
-        # and once more with the index work prepared ahead on the auxiliary stream
-        tr.prepare(0, *batches[0])
-        tr.prepare(1, *batches[1])
+        # and once more with the index work prepared ahead on the auxiliary stream: two different batches
+        # back to back behind a busy main stream (the preparations read their index arrays only once that work
+        # has drained, long after prepare() has returned), given as int64 (prepare casts)
+        x = torch.randn(4096, 4096, device=cuda)
+        for _ in range(30):
+            x = (x @ x).clamp_(-1, 1)
+        tr.prepare(0, *[t.long() for t in batches[0]])
+        tr.prepare(1, *[t.long() for t in batches[1]])
         tr.step_prepared(0)
         tr.step_prepared(1)
         batches = batches + batches[:2]

@@ -140,3 +140,27 @@ def test_apr_step_vs_autograd(oracle, golden_steps, name):
         np.testing.assert_allclose(arr, g["apr_%s_%s" % (name, k)], rtol=1e-6, atol=1e-9)
     for arr, k in ((P, "P1"), (Q, "Q1"), (b, "b1"), (aP, "aP1"), (aQ, "aQ1"), (ab, "ab1")):
         np.testing.assert_allclose(arr, g["apr_%s_%s" % (name, k)], rtol=1e-6, atol=1e-8)
+
+
+def test_multithreaded_oracle_step_equals_the_scalar_one(oracle):
+    """oracle_bpr_step_mt (the benchmark's multi-core CPU baseline) leaves the same bits in every parameter as
+    oracle_bpr_step, with hot items and duplicate users, and leaves the shared accumulators clean."""
+    rng = np.random.default_rng(11)
+    U, I, d, B = 700, 300, 20, 6000
+    P = rng.uniform(-0.3, 0.3, (U, d)).astype(np.float32)
+    Q = rng.uniform(-0.3, 0.3, (I, d)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, I).astype(np.float32)
+    u = rng.integers(0, U, B).astype(np.int32)
+    i = (rng.zipf(1.3, B) % I).astype(np.int32)
+    j = rng.integers(0, I, B).astype(np.int32)
+    ws = oracle.Workspace(U, I, d)
+    a = [x.copy() for x in (P, Q, b)]
+    la = oracle.bpr_step(*a, u, i, j, 0.01, 0.05, ws=ws)
+    for threads in (2, 3, 8):
+        c = [x.copy() for x in (P, Q, b)]
+        lc = oracle.bpr_step(*c, u, i, j, 0.01, 0.05, ws=ws, threads=threads)
+        assert all(np.array_equal(x, y) for x, y in zip(a, c))
+        np.testing.assert_allclose(lc, la, rtol=1e-12)
+    e = [x.copy() for x in (P, Q, b)]
+    oracle.bpr_step(*e, u, i, j, 0.01, 0.05, ws=ws)
+    assert all(np.array_equal(x, y) for x, y in zip(a, e))

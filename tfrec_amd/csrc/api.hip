@@ -51,10 +51,11 @@ void *tfrec_ws_take(tfrec_ctx *ctx, size_t bytes)
 int tfrec_pinned_require(tfrec_ctx *ctx, size_t bytes)
 {
     if (bytes <= ctx->h_pinned_bytes) return TFREC_OK;
-    if (ctx->h_pinned) TF_HIP(hipHostFree(ctx->h_pinned));
-    ctx->h_pinned = nullptr;
+    void *old = ctx->h_pinned;
+    ctx->h_pinned = nullptr;          // whatever hipHostFree says, the old block is not used again
     ctx->h_pinned_bytes = 0;
     ctx->pinned_tab_k = 0;
+    if (old) TF_HIP(hipHostFree(old));
     const size_t want = tf_align(bytes, 4096);
     TF_HIP(hipHostMalloc(&ctx->h_pinned, want, hipHostMallocDefault));
     ctx->h_pinned_bytes = want;
@@ -71,17 +72,25 @@ extern "C" int tfrec_ctx_create(int device, void *hip_stream, tfrec_ctx **out)
     tfrec_ctx *c = new (std::nothrow) tfrec_ctx();
     TF_REQUIRE(c != nullptr, TFREC_ENOMEM, "host allocation failed");
     c->device = device;
+    // a failure below releases whatever the partial context already owns
+    auto fail = [&](int code, const char *what, hipError_t e) {
+        tfrec_set_error("%s: %s", what, hipGetErrorString(e));
+        if (c->d_flags) (void)hipFree(c->d_flags);
+        if (c->own_stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+        return code;
+    };
     if (hip_stream) {
         c->stream = (hipStream_t)hip_stream;
     } else {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-        if (e != hipSuccess) { delete c; tfrec_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return TFREC_EHIP; }
+        if (e != hipSuccess) return fail(TFREC_EHIP, "hipStreamCreate", e);
         c->own_stream = true;
     }
     hipError_t e = hipMalloc((void **)&c->d_flags, 256);
-    if (e != hipSuccess) { delete c; tfrec_set_error("hipMalloc(flags): %s", hipGetErrorString(e)); return TFREC_ENOMEM; }
+    if (e != hipSuccess) { c->d_flags = nullptr; return fail(TFREC_ENOMEM, "hipMalloc(flags)", e); }
     e = hipMemsetAsync(c->d_flags, 0, 256, c->stream);
-    if (e != hipSuccess) { delete c; tfrec_set_error("hipMemset(flags): %s", hipGetErrorString(e)); return TFREC_EHIP; }
+    if (e != hipSuccess) return fail(TFREC_EHIP, "hipMemset(flags)", e);
     *out = c;
     return TFREC_OK;
 }

@@ -20,8 +20,9 @@
 // documented replacement and makes item-sharded results merge exactly.
 #include "common.hpp"
 
+#include <atomic>
 #include <cmath>
-#include <vector>
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -928,11 +929,14 @@ template <int D, bool BF16, int CAP>
 static int launch_score(tfrec_ctx *ctx, const ScoreArgs &a, int user_blocks, int splits)
 {
     using G = ScoreGeom<D, BF16, CAP>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the dynamic-LDS limit is a per-device attribute of the kernel: set once on every device this
+    // instantiation runs on (bit = device ordinal; devices beyond 63 set it on every launch)
+    static std::atomic<uint64_t> attr_devices{0};
+    const uint64_t dev_bit = ctx->device < 64 ? (1ull << ctx->device) : 0ull;
+    if (!(attr_devices.load(std::memory_order_acquire) & dev_bit)) {
         TF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&score_topk_kernel<D, BF16, CAP>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
-        attr_set = true;
+        attr_devices.fetch_or(dev_bit, std::memory_order_release);
     }
     // the caller counts workgroups of 128 users; this instantiation may hold more
     constexpr int UB = 32 * G::NW * ScoreWave<D, BF16, CAP>::UW;
@@ -1242,13 +1246,21 @@ static int metrics_to_host(tfrec_ctx *ctx, const int32_t *d_ids, const int32_t *
     TF_TRY(metrics_sums(ctx, d_ids, d_users, n, k, tptr, tidx, rows, d_sums));
     if (mean_mode == 1) {
         // per-user rows to the host, summed sequentially in float32 in user order (evaluate.h:40-92)
-        std::vector<float> host((size_t)n * C);
-        TF_HIP(hipMemcpyAsync(host.data(), rows, sizeof(float) * (size_t)n * C, hipMemcpyDeviceToHost, ctx->stream));
-        TF_HIP(hipStreamSynchronize(ctx->stream));
+        // (malloc, not a container: an allocation failure is reported, nothing can throw across the C boundary)
+        float *host = (float *)std::malloc(sizeof(float) * (size_t)n * C);
+        TF_REQUIRE(host != nullptr, TFREC_ENOMEM, "host allocation of %zu bytes for the per-user metric rows failed", sizeof(float) * (size_t)n * C);
+        hipError_t e = hipMemcpyAsync(host, rows, sizeof(float) * (size_t)n * C, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            std::free(host);
+            tfrec_set_error("copy of the per-user metric rows failed: %s", hipGetErrorString(e));
+            return TFREC_EHIP;
+        }
         for (int c = 0; c < C; ++c) h_mean[c] = 0.f;
         for (int64_t u = 0; u < n; ++u)
             for (int c = 0; c < C; ++c) h_mean[c] += host[(size_t)u * C + c];
         for (int c = 0; c < C; ++c) h_mean[c] /= (float)n;
+        std::free(host);
         return TFREC_OK;
     }
     double *h = (double *)ctx->h_pinned + k;

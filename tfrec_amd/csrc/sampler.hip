@@ -91,13 +91,25 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(const int64_t *__
     }
 }
 
-__global__ __launch_bounds__(256) void shuffle_keys_kernel(int64_t n, uint64_t seed, uint64_t stream, uint32_t *__restrict__ keys,
-                                                           uint32_t *__restrict__ vals)
+// The shuffle orders the elements by a 64-bit hash key in two stable 32-bit sorts: by the low word first, then by
+// the high word.  (With 32-bit keys alone about n*n / 2^33 pairs would tie -- a million at 10^8 elements -- and keep
+// their storage order; 64-bit keys tie about n*n / 2^65 times.)
+__global__ __launch_bounds__(256) void shuffle_keys_lo_kernel(int64_t n, uint64_t seed, uint64_t stream, uint32_t *__restrict__ keys,
+                                                              uint32_t *__restrict__ vals)
 {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
-    keys[t] = (uint32_t)(draw64(seed, stream ^ 0x73687566666c65ull, (uint64_t)t, 0) >> 32);
+    keys[t] = (uint32_t)draw64(seed, stream ^ 0x73687566666c65ull, (uint64_t)t, 0);
     vals[t] = (uint32_t)t;
+}
+
+// high key words of the elements in the order the first sort left them
+__global__ __launch_bounds__(256) void shuffle_keys_hi_kernel(int64_t n, uint64_t seed, uint64_t stream, const uint32_t *__restrict__ vals,
+                                                              uint32_t *__restrict__ keys)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    keys[t] = (uint32_t)(draw64(seed, stream ^ 0x73687566666c65ull, (uint64_t)vals[t], 0) >> 32);
 }
 
 __global__ __launch_bounds__(256) void gather_rows_i32_kernel(const int32_t *__restrict__ src, const int32_t *__restrict__ perm, int64_t n,
@@ -136,15 +148,19 @@ extern "C" int tfrec_shuffle_perm(tfrec_ctx *ctx, int64_t n, uint64_t seed, uint
     if (n == 0) return TFREC_OK;
     TF_REQUIRE(d_perm_out != nullptr, TFREC_EINVAL, "null output");
     const size_t sort_bytes = tfrec_sort_temp_bytes((size_t)n, 32);
-    TF_TRY(tfrec_ws_require(ctx, ctx->ws_used + 3 * tf_align(4 * (size_t)n) + tf_align(sort_bytes) + 1024));
+    TF_TRY(tfrec_ws_require(ctx, ctx->ws_used + 4 * tf_align(4 * (size_t)n) + tf_align(sort_bytes) + 1024));
     uint32_t *keys = (uint32_t *)tfrec_ws_take(ctx, 4 * (size_t)n), *vals = (uint32_t *)tfrec_ws_take(ctx, 4 * (size_t)n);
-    uint32_t *keys_sorted = (uint32_t *)tfrec_ws_take(ctx, 4 * (size_t)n);
+    uint32_t *keys_sorted = (uint32_t *)tfrec_ws_take(ctx, 4 * (size_t)n), *vals_lo = (uint32_t *)tfrec_ws_take(ctx, 4 * (size_t)n);
     void *tmp = tfrec_ws_take(ctx, sort_bytes);
     TF_REQUIRE(tmp != nullptr, TFREC_ENOMEM, "internal: workspace carve failed");
-    shuffle_keys_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(n, seed, stream, keys, vals);
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    shuffle_keys_lo_kernel<<<blocks, 256, 0, ctx->stream>>>(n, seed, stream, keys, vals);
     TF_HIP(hipGetLastError());
-    // equal keys keep their original order (the sort is stable), so the permutation is a function of (seed, stream, n)
-    return tfrec_sort_pairs(tmp, sort_bytes, keys, keys_sorted, vals, reinterpret_cast<uint32_t *>(d_perm_out), (size_t)n, 32, ctx->stream);
+    TF_TRY(tfrec_sort_pairs(tmp, sort_bytes, keys, keys_sorted, vals, vals_lo, (size_t)n, 32, ctx->stream));
+    shuffle_keys_hi_kernel<<<blocks, 256, 0, ctx->stream>>>(n, seed, stream, vals_lo, keys);
+    TF_HIP(hipGetLastError());
+    // equal 64-bit keys keep their original order (both sorts are stable), so the permutation is a function of (seed, stream, n)
+    return tfrec_sort_pairs(tmp, sort_bytes, keys, keys_sorted, vals_lo, reinterpret_cast<uint32_t *>(d_perm_out), (size_t)n, 32, ctx->stream);
 }
 
 extern "C" int tfrec_gather_rows_i32(tfrec_ctx *ctx, const int32_t *d_src, int64_t n_src, const int32_t *d_perm, int64_t n, int width,

@@ -195,6 +195,7 @@ class ShardedBprTrainer:
             self.b = torch.zeros(max(ni, 1), dtype=torch.float32, device=device)[:ni]
         assert self.P.shape[0] == nu and self.Q.shape[0] == ni
         self._mark = None
+        self._pending = {}          # slot -> index tensors of a prepared batch, alive until its step is enqueued
 
     def _init_rows(self, n_total, rng, seed):
         return self.backend.uniform_rows(rng[0], rng[1], self.d, -0.05, 0.05, seed, self.device)
@@ -214,8 +215,13 @@ class ShardedBprTrainer:
         """Dense mode: sorts the index arrays of an upcoming batch on the library's auxiliary stream
         (slot 0 or 1), beside whatever the main stream is doing; ``step_prepared(slot)`` consumes it."""
         assert self.item_mode == "dense"
-        self.backend.prepare_batch(slot, self.user_range[1] - self.user_range[0], self.I,
-                                   (users.to(torch.int32) - self.user_range[0]).contiguous(), pos.contiguous(), neg.contiguous())
+        u = (users.to(torch.int32) - self.user_range[0]).contiguous()
+        p, n = pos.to(torch.int32).contiguous(), neg.to(torch.int32).contiguous()
+        # The library reads these arrays on its auxiliary stream, which torch's allocator knows nothing about:
+        # they are kept until the step that consumes the slot has been enqueued on the main stream (that step
+        # waits for the preparation, so whatever reuses the memory afterwards is ordered behind the reads).
+        self._pending[slot] = (u, p, n)
+        self.backend.prepare_batch(slot, self.user_range[1] - self.user_range[0], self.I, u, p, n)
 
     def step_prepared(self, slot, prepare_next=None):
         """Consumes the batch prepared in ``slot``.  ``prepare_next`` = (slot, users, pos, neg) of the
@@ -228,6 +234,8 @@ class ShardedBprTrainer:
             users = (users.to(torch.int32) - self.user_range[0]).contiguous()
             pos, neg = pos.to(torch.int32).contiguous(), neg.to(torch.int32).contiguous()
         self.backend.bpr_dense_grad_step(self.P, self.Q_full, self.b_full, self._G, users, pos, neg, self.lr, self.reg, slot=slot)
+        if slot >= 0:
+            self._pending.pop(slot, None)        # consumed: the step that read the slot is enqueued
         if prepare_next is not None:
             self.prepare(*prepare_next)
         if self.world > 1:
