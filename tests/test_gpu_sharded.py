@@ -278,3 +278,112 @@ def test_two_ranks_apr_match_one_rank(tmp_path):
     np.testing.assert_allclose(r["Q"], Q.numpy(), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(r["b"], b.numpy(), rtol=1e-4, atol=1e-6)
     dev.close()
+
+
+# ---- the large configuration's layout: every table row-sharded, DNS pools of 32, item-sharded evaluation ------
+C4 = dict(U=6000, I=4000, d=128, C=32, B=8192, k=100, seed=29)
+
+
+def _c4_matrix():
+    import scipy.sparse as sp
+    rng = np.random.default_rng(C4["seed"])
+    rows, cols = [], []
+    for u in range(C4["U"]):
+        c = rng.permutation(C4["I"])[: int(rng.integers(1, 14))]
+        rows += [u] * len(c); cols += c.tolist()
+    m = sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(C4["U"], C4["I"])); m.sort_indices()
+    return m
+
+
+def _c4_eval_inputs(cuda):
+    rng = np.random.default_rng(C4["seed"] + 1)
+    U, I = C4["U"], C4["I"]
+    m = _c4_matrix()
+    tptr = torch.from_numpy(m.indptr.astype(np.int64)).to(cuda)
+    tidx = torch.from_numpy(m.indices.astype(np.int32)).to(cuda)
+    eptr = torch.arange(0, 3 * (U + 1), 3, dtype=torch.int64, device=cuda)
+    eidx = torch.from_numpy(np.sort(rng.integers(0, I, (U, 3)), axis=1).astype(np.int32).ravel()).to(cuda)
+    users = torch.arange(0, U, 2, dtype=torch.int32, device=cuda)
+    return (tptr, tidx), (eptr, eidx), users
+
+
+def _two_rank_c4_worker(rank, world, port, out_dir):
+    import os
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from test_gpu_sharded import C4, _c4_matrix, _c4_eval_inputs
+    from tfrec_amd.device import SCORE_BF16
+    from tfrec_amd.sharded import ShardedBprTrainer, ShardedEpochSampler, ShardedEvaluator, make_device
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    dev = make_device(0)
+    cuda = torch.device("cuda", 0)
+    tr = ShardedBprTrainer(dev, C4["U"], C4["I"], C4["d"], 0.05, 0.01, seed=C4["seed"], item_mode="sharded")
+    s = ShardedEpochSampler(dev, tr, _c4_matrix(), seed=C4["seed"], n_neg=C4["C"])
+    start = [x.cpu().numpy() for x in tr.gather_full()]
+    lists = []
+    for e in range(2):
+        eu, ep, en = s.epoch(e)          # what train_epoch draws (a pure function of the epoch and the model at its start)
+        lists.append(np.stack([x.cpu().numpy() for x in (eu, ep, en)]) if s.nnz else np.zeros((3, 0), np.int32))
+        s.train_epoch(e, C4["B"])
+    P, Q, b = tr.gather_full()
+    train, test, users = _c4_eval_inputs(cuda)
+    m32 = ShardedEvaluator(dev, tr, train, test, users, top_k=C4["k"], chunk_users=1000).evaluate()
+    m16 = ShardedEvaluator(dev, tr, train, test, users, top_k=C4["k"], chunk_users=1000, mode=SCORE_BF16).evaluate()
+    dev.synchronize()
+    np.savez(os.path.join(out_dir, "c4_r%d.npz" % rank), P=P.cpu().numpy(), Q=Q.cpu().numpy(), b=b.cpu().numpy(),
+             P0=start[0], Q0=start[1], b0=start[2], l0=lists[0], l1=lists[1], m32=m32.cpu().numpy(), m16=m16.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+    dev.close()
+
+
+def test_two_ranks_all_tables_sharded_dns_epochs_and_item_sharded_eval(tmp_path, oracle):
+    """World size 2 with the HIP backend on both ranks (one GPU, gloo between them), every table row-sharded
+    (all-to-all lookups), DNS pools of 32 candidates, d=128, item-sharded evaluation at k=100: the epoch lists are
+    the whole matrix's draws with the best candidate under the epoch-start model, the parameters after two
+    collective epochs are those of one GPU stepping over the union of the ranks' batches, and the sharded
+    metrics are those of the unsharded evaluation of the same model."""
+    import socket
+    import torch.multiprocessing as mp
+    from tfrec_amd.device import Device, SCORE_BF16
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_two_rank_c4_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    rs = [np.load(str(tmp_path / ("c4_r%d.npz" % r))) for r in range(2)]
+    U, I, d, C, B, k = (C4[x] for x in ("U", "I", "d", "C", "B", "k"))
+    dev = Device(0)
+    # epoch 0: pools drawn for the whole matrix, best candidate under the initial model (same kernel arithmetic)
+    m = _c4_matrix()
+    wu, wp, pools, _ = oracle.sample_negatives(m.indptr.astype(np.int64), m.indices.astype(np.int32), U, I, C, C4["seed"], 0)
+    P0, Q0, b0 = (dev.array(rs[0][x]) for x in ("P0", "Q0", "b0"))
+    want = dev.dns_select(P0, Q0, b0, dev.array(wu, np.int32), dev.array(pools, np.int32)).numpy()
+    got = np.concatenate([r["l0"] for r in rs], axis=1)
+    key = lambda a: np.lexsort((a[2], a[1], a[0]))
+    ref = np.stack([wu, wp, want])
+    assert got.shape == ref.shape
+    assert np.array_equal(got[:, key(got)], ref[:, key(ref)])
+    # the two epochs replayed on one GPU over the union of the ranks' batches
+    P, Q, b = P0, Q0, b0
+    for e in range(2):
+        lists = [r["l%d" % e] for r in rs]
+        steps = max((l.shape[1] + B - 1) // B for l in lists)
+        for st in range(steps):
+            part = [l[:, st * B:(st + 1) * B] for l in lists]
+            uu, ii, jj = (np.ascontiguousarray(np.concatenate([x[c] for x in part]), dtype=np.int32) for c in range(3))
+            dev.bpr_sgd_step(P, Q, b, dev.array(uu), dev.array(ii), dev.array(jj), 0.05, 0.01)
+    dev.synchronize()
+    for name, t in (("P", P), ("Q", Q), ("b", b)):
+        np.testing.assert_allclose(rs[0][name], t.numpy(), rtol=1e-5, atol=1e-7, err_msg=name)
+        assert np.array_equal(rs[0][name], rs[1][name])
+    # the sharded metrics against the unsharded evaluation of the two-rank model
+    cuda = torch.device("cuda", 0)
+    train, test, users = _c4_eval_inputs(cuda)
+    P2, Q2, b2 = (torch.from_numpy(rs[0][x]).to(cuda) for x in ("P", "Q", "b"))
+    for mode, name in ((0, "m32"), (SCORE_BF16, "m16")):
+        ref = dev.eval_fullrank(P2, Q2, b2, users, train, test, k, mode=mode, mean_mode=0)
+        np.testing.assert_allclose(rs[0][name], ref, rtol=1e-6, atol=1e-7, err_msg=name)
+        assert np.array_equal(rs[0][name], rs[1][name])
+    dev.close()

@@ -304,7 +304,17 @@ def _sum_rows(n_rows, idx_vals):
 
 
 def test_full_size_step_against_float64_sums(dev):
-    """The bench workload at its full size (1M users x 200k items, d=64, 4M triples, Zipf positives): every
+    _full_size_step_check(1_000_000, 200_000, 64, 1 << 22)
+
+
+def test_full_size_step_10m_users_2m_items_d128(dev):
+    """The large configuration's table shape on one GPU (10M users x 2M items, d=128: 6.1 GB of tables that no
+    cache holds), 2M triples: same checks as at the bench size."""
+    _full_size_step_check(10_000_000, 2_000_000, 128, 1 << 21)
+
+
+def _full_size_step_check(U, I, d, B):
+    """A BPR step at full size (the bench workload: 1M users x 200k items, d=64, 4M triples, Zipf positives): every
     row of P, Q and b after one step against an independent float64 statement of model/BPR.py:36-48 built
     from torch gathers and sorted segment sums on the same device, plus two size-independent properties: a step with
     lr = 0 leaves every parameter bit for bit, and without regularisation the biases only move mass between
@@ -315,7 +325,7 @@ def test_full_size_step_against_float64_sums(dev):
     stream = torch.cuda.Stream(device=cuda)
     with torch.cuda.stream(stream):
         d2 = Device(0, stream=stream.cuda_stream)
-        U, I, d, B, lr, reg = 1_000_000, 200_000, 64, 1 << 22, 0.01, 0.05
+        lr, reg = 0.01, 0.05
         g = torch.Generator(device=cuda); g.manual_seed(99)
         P = (torch.rand(U, d, device=cuda, generator=g) - 0.5) * 0.6
         Q = (torch.rand(I, d, device=cuda, generator=g) - 0.5) * 0.6
