@@ -382,6 +382,12 @@ def main():
                 def step(s):
                     trainer.step(*batch(s))
 
+        def max_over_ranks(x):
+            # (a host tensor under gloo, whose handling of device tensors is unreliable with ranks that share a GPU)
+            t = torch.tensor([x], device=cuda if args.backend == "nccl" else "cpu", dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            return float(t.item())
+
         def barrier():
             if world > 1:
                 torch.distributed.barrier()
@@ -400,9 +406,7 @@ def main():
         wall = time.perf_counter() - t0
         dev_ms = e0.elapsed_time(e1)
         if world > 1:
-            tmax = torch.tensor([wall], device=cuda, dtype=torch.float64)
-            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-            wall = float(tmax.item())
+            wall = max_over_ranks(wall)
         dev.synchronize()        # raises if any batch held an out-of-range index
 
         ms_per_step = wall * 1e3 / args.steps
@@ -461,9 +465,7 @@ def main():
                     barrier()
                     dt = time.perf_counter() - t1
                     if world > 1:
-                        tm = torch.tensor([dt], device=cuda, dtype=torch.float64)
-                        torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
-                        dt = float(tm.item())
+                        dt = max_over_ranks(dt)
                     tf = 2.0 * I * d * n / dt / 1e12
                     ev[name] = {"users_per_s": n / dt, "ms": dt * 1e3, "users": n, "items": I, "topk": k, "layout": se.layout + "-sharded",
                                 "roofline": {"bound": "mfma", "achieved": tf / world, "peak": MFMA_PEAK_TFLOPS[name], "unit": "TFLOP/s per GPU",
@@ -486,9 +488,7 @@ def main():
                 barrier()
                 dt = time.perf_counter() - t1
                 if world > 1:
-                    tm = torch.tensor([dt], device=cuda, dtype=torch.float64)
-                    torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
-                    dt = float(tm.item())
+                    dt = max_over_ranks(dt)
                 apr_bytes = 84 * d + 68
                 per_gpu = B * apr_bytes / (dt / apr_steps) / 1e9
                 res = {"apr_adagrad_step": {

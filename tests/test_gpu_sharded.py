@@ -315,6 +315,8 @@ def _two_rank_c4_worker(rank, world, port, out_dir):
     for p in (root, os.path.join(root, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=True)      # a stuck collective names itself instead of hanging the run
     from test_gpu_sharded import C4, _c4_matrix, _c4_eval_inputs
     from tfrec_amd.device import SCORE_BF16
     from tfrec_amd.sharded import ShardedBprTrainer, ShardedEpochSampler, ShardedEvaluator, make_device

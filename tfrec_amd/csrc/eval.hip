@@ -897,6 +897,100 @@ __global__ __launch_bounds__(256) void metrics_user_kernel(const int32_t *__rest
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// metric SUMS over users without the per-user rows (what an evaluation needs when nobody asked for
+// the [n, 5, k] curves): one lane per user walks its rank list once; for every rank position the
+// wave adds up its 64 users -- hits and first hits as ballot counts, the recall and average-precision
+// terms (whose weights differ per user) as float64 butterfly sums -- and the four per-position arrays
+// of a wave are combined per workgroup, then over workgroups, in a fixed order.  metrics_final_kernel
+// turns them into the five curves' sums:
+//   precision@t = H_t/(t+1), ndcg@t = DCG_t/IDCG_t and mrr@t are prefix sums of the hit / first-hit
+//   counts (evaluator/backend/cpp/metrics.h:11-25, 59-100); recall@t and map@t are summed per user as
+//   metrics.h:27-57 rounds them (float per user and position), in float64 over users.
+// ------------------------------------------------------------------------------------------
+constexpr int METRIC_KMAX = 240;
+
+__global__ __launch_bounds__(256) void metrics_sums_kernel(const int32_t *__restrict__ ids, const int32_t *__restrict__ users,
+                                                           int64_t n, int k, const int64_t *__restrict__ tptr,
+                                                           const int32_t *__restrict__ tidx, double *__restrict__ block_part)
+{
+    // per wave and position: [0] hits, [1] first hits, [2] sum of recall terms, [3] sum of average-precision terms
+    __shared__ double part[4][4][METRIC_KMAX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = r < n;
+    int64_t lo = 0, hi = 0;
+    if (valid) {
+        const int32_t u = users[r];
+        lo = tptr[u];
+        hi = tptr[u + 1];
+    }
+    const int n_truth = (int)(hi - lo);
+    const int32_t *rank = ids + (size_t)(valid ? r : 0) * k;
+    int hits = 0;
+    bool had = false;
+    float sum_pre = 0.f;
+    for (int i = 0; i < k; ++i) {
+        const int32_t id = valid ? rank[i] : -1;
+        const bool hit = id >= 0 && csr_row_contains(tidx, lo, hi, id);
+        hits += hit;
+        const float p = (float)(1.0 * hits / (i + 1));
+        if (hit) sum_pre += p;
+        double rec = valid ? (double)(float)(1.0 * hits / n_truth) : 0.0;
+        double ap = valid ? (double)(float)(1.0 * (double)sum_pre / (n_truth < i + 1 ? n_truth : i + 1)) : 0.0;
+        const int c_hit = __popcll(__ballot(hit));
+        const int c_first = __popcll(__ballot(hit && !had));
+        had = had || hit;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) {
+            rec += __shfl_xor(rec, m, 64);
+            ap += __shfl_xor(ap, m, 64);
+        }
+        if (lane == 0) {
+            part[wave][0][i] = (double)c_hit;
+            part[wave][1][i] = (double)c_first;
+            part[wave][2][i] = rec;
+            part[wave][3][i] = ap;
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 4 * k; e += 256) {
+        const int q = e / k, i = e - q * k;
+        block_part[(size_t)blockIdx.x * 4 * k + e] = (part[0][q][i] + part[1][q][i]) + (part[2][q][i] + part[3][q][i]);
+    }
+}
+
+// block_part [n_blocks][4k] -> sums [5k] (accumulated onto the existing sums when `accumulate`); one workgroup.
+__global__ __launch_bounds__(256) void metrics_final_kernel(const double *__restrict__ block_part, int n_blocks, int k,
+                                                            const double *__restrict__ inv_log2, double *__restrict__ sums, int accumulate)
+{
+    __shared__ double col[4][METRIC_KMAX];
+    // column sums over workgroups: four partial sums per column (one per wave), combined in a fixed order
+    __shared__ double quarter[4][4 * METRIC_KMAX];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int per = (n_blocks + 3) / 4, b0 = wave * per, b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
+    for (int e = lane; e < 4 * k; e += 64) {
+        double v = 0.0;
+        for (int b = b0; b < b1; ++b) v += block_part[(size_t)b * 4 * k + e];
+        quarter[wave][e] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 4 * k; e += 256)
+        col[e / k][e % k] = (quarter[0][e] + quarter[1][e]) + (quarter[2][e] + quarter[3][e]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double H = 0.0, dcg = 0.0, idcg = 0.0, mrr = 0.0;
+        for (int i = 0; i < k; ++i) {
+            H += col[0][i];
+            dcg += col[0][i] * inv_log2[i];
+            idcg += inv_log2[i];
+            mrr += col[1][i] / (double)(i + 1);
+            const double v[5] = {H / (double)(i + 1), col[2][i], col[3][i], dcg / idcg, mrr};
+            for (int m = 0; m < 5; ++m) sums[m * k + i] = (accumulate ? sums[m * k + i] : 0.0) + v[m];
+        }
+    }
+}
+
 // column sums of per_user [n, C] in a fixed order: grid (column chunk, user chunk)
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ per_user, int64_t n, int C, int64_t users_per_chunk,
                                                      double *__restrict__ partial)
@@ -1167,29 +1261,31 @@ extern "C" int tfrec_topk_dense(tfrec_ctx *ctx, const float *d_ratings, int64_t 
     return TFREC_OK;
 }
 
-// per-user curves + column sums; leaves [5k] double sums in d_sums.  Scratch is carved above
-// whatever the caller already holds in the workspace.
+// Leaves [5k] double sums over the users in d_sums: from the per-user curves when the caller wants those rows
+// (d_per_user), else straight from the rank lists.  Scratch is carved above whatever the caller already holds
+// in the workspace.
 static size_t metrics_need(int64_t n, int k, bool have_rows)
 {
+    if (!have_rows) return tf_align(sizeof(double) * (size_t)((n + 255) / 256) * 4 * k) + tf_align(sizeof(double) * k) + 4096;
     const int C = 5 * k;
-    const int64_t chunk = have_rows ? n : (n < (1 << 18) ? n : (1 << 18));
-    const int64_t max_chunks = (chunk + 1023) / 1024;
-    return (have_rows ? 0 : tf_align(sizeof(float) * (size_t)chunk * C)) + tf_align(sizeof(double) * (size_t)max_chunks * C) +
-           tf_align(sizeof(double) * k) + 4096;
+    const int64_t max_chunks = (n + 1023) / 1024;
+    return tf_align(sizeof(double) * (size_t)max_chunks * C) + tf_align(sizeof(double) * k) + 4096;
 }
 
 static int metrics_sums(tfrec_ctx *ctx, const int32_t *d_ids, const int32_t *d_users, int64_t n, int k, const int64_t *tptr,
                         const int32_t *tidx, float *d_per_user, double *d_sums)
 {
     const int C = 5 * k;
-    const int64_t chunk = d_per_user ? n : (n < (1 << 18) ? n : (1 << 18));   // users per pass when the rows are scratch
+    TF_REQUIRE(k <= METRIC_KMAX, TFREC_EUNSUP, "metrics beyond top-%d are not supported (k=%d)", METRIC_KMAX, k);
+    const int64_t chunk = n;
     const int64_t upc = 1024;                                                  // users per column-sum block
     const int64_t max_chunks = (chunk + upc - 1) / upc;
     TF_TRY(tfrec_ws_require(ctx, ctx->ws_used + metrics_need(n, k, d_per_user != nullptr)));
-    float *rows = d_per_user ? d_per_user : (float *)tfrec_ws_take(ctx, sizeof(float) * (size_t)chunk * C);
-    double *partial = (double *)tfrec_ws_take(ctx, sizeof(double) * (size_t)max_chunks * C);
+    float *rows = d_per_user;
+    const int64_t n_blocks = (n + 255) / 256;
+    double *partial = (double *)tfrec_ws_take(ctx, d_per_user ? sizeof(double) * (size_t)max_chunks * C : sizeof(double) * (size_t)n_blocks * 4 * k);
     double *tab = (double *)tfrec_ws_take(ctx, sizeof(double) * k);
-    TF_REQUIRE(rows && partial && tab, TFREC_ENOMEM, "internal: workspace carve failed");
+    TF_REQUIRE(partial && tab, TFREC_ENOMEM, "internal: workspace carve failed");
     // 1/log2(i+2) from the host's libm, so the device adds exactly the doubles metrics.h:69-71 adds
     TF_TRY(tfrec_pinned_require(ctx, sizeof(double) * (k + C)));
     double *h_tab = (double *)ctx->h_pinned;
@@ -1199,6 +1295,15 @@ static int metrics_sums(tfrec_ctx *ctx, const int32_t *d_ids, const int32_t *d_u
         ctx->pinned_tab_k = k;
     }
     TF_HIP(hipMemcpyAsync(tab, h_tab, sizeof(double) * k, hipMemcpyHostToDevice, ctx->stream));
+    if (!d_per_user) {
+        // nobody wants the per-user curves: sums only, no [n, 5, k] table
+        TF_REQUIRE(n_blocks < (1ll << 31), TFREC_EUNSUP, "too many users for one metrics launch");
+        metrics_sums_kernel<<<(unsigned)n_blocks, 256, 0, ctx->stream>>>(d_ids, d_users, n, k, tptr, tidx, partial);
+        TF_HIP(hipGetLastError());
+        metrics_final_kernel<<<1, 256, 0, ctx->stream>>>(partial, (int)n_blocks, k, tab, d_sums, 0);
+        TF_HIP(hipGetLastError());
+        return TFREC_OK;
+    }
     for (int64_t u0 = 0; u0 < n; u0 += chunk) {
         const int64_t nn = n - u0 < chunk ? n - u0 : chunk;
         float *rp = d_per_user ? d_per_user + (size_t)u0 * C : rows;

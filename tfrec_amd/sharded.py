@@ -40,12 +40,53 @@ import torch.distributed as dist
 DENSE_ITEM_BYTES = 256 << 20     # item tables up to this size are replicated rather than sharded
 
 
-def _drain_for_gloo(t, group=None):
-    """gloo moves device tensors through host memory on its own threads; with two ranks on one GPU
-    that has been seen to stall unless the producing stream is drained first.  RCCL orders itself
-    on the stream and needs nothing."""
-    if t.is_cuda and dist.is_initialized() and dist.get_backend(group) == "gloo":
-        torch.cuda.synchronize(t.device)
+def _via_host(t, group=None):
+    """True under gloo with a device tensor: gloo's own handling of device tensors was seen to hang with two
+    ranks on one GPU (the test set-up), so those collectives are staged through host memory here.  RCCL takes
+    device tensors as they are and orders itself on the stream."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_reduce(t, group=None, op=None):
+    op = op if op is not None else dist.ReduceOp.SUM
+    if _via_host(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
+def _all_gather(x, world, group=None):
+    """List of every rank's ``x`` (equal shapes)."""
+    x = x.contiguous()
+    if _via_host(x, group):
+        h = x.cpu()
+        outs = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(outs, h, group=group)
+        return [o.to(x.device) for o in outs]
+    outs = [torch.empty_like(x) for _ in range(world)]
+    dist.all_gather(outs, x, group=group)
+    return outs
+
+
+def _broadcast(t, src, group=None):
+    if _via_host(t, group):
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+
+
+def _all_to_all_rows(out, send, recv_counts, send_counts, group=None):
+    """all_to_all_single with per-rank row counts."""
+    if _via_host(send, group):
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(h_out, send.contiguous().cpu(), list(recv_counts), list(send_counts), group=group)
+        out.copy_(h_out)
+        return
+    dist.all_to_all_single(out, send.contiguous(), list(recv_counts), list(send_counts), group=group)
 
 
 def _part(n, world):
@@ -207,8 +248,7 @@ class ShardedBprTrainer:
         if self.world == 1:
             out.copy_(send)
             return out
-        _drain_for_gloo(send, self.group)
-        dist.all_to_all_single(out, send.contiguous(), list(recv_counts), list(send_counts), group=self.group)
+        _all_to_all_rows(out, send, recv_counts, send_counts, self.group)
         return out
 
     def prepare(self, slot, users, pos, neg):
@@ -239,8 +279,7 @@ class ShardedBprTrainer:
         if prepare_next is not None:
             self.prepare(*prepare_next)
         if self.world > 1:
-            _drain_for_gloo(self._G, self.group)
-            dist.all_reduce(self._G, group=self.group)
+            _all_reduce(self._G, self.group)
         self.backend.axpy(self._Qb, self._G, -self.lr)
 
     def step(self, users, pos, neg):
@@ -268,7 +307,7 @@ class ShardedBprTrainer:
         # (2) how many ids each owner will be asked for
         if W > 1:
             recv_counts = torch.empty_like(send_counts)
-            dist.all_to_all_single(recv_counts, send_counts, group=self.group)
+            _all_to_all_rows(recv_counts, send_counts, [1] * W, [1] * W, self.group)
         else:
             recv_counts = send_counts.clone()
         sc, rc = send_counts.tolist(), recv_counts.tolist()
@@ -301,9 +340,7 @@ class ShardedBprTrainer:
         def cat(x):
             pad = torch.zeros((self.ipr,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
             pad[: x.shape[0]] = x
-            outs = [torch.empty_like(pad) for _ in range(self.world)]
-            _drain_for_gloo(pad, self.group)
-            dist.all_gather(outs, pad, group=self.group)
+            outs = _all_gather(pad, self.world, self.group)
             return torch.cat(outs)[: self.I].contiguous()
         return cat(self.Q), cat(self.b)
 
@@ -315,9 +352,7 @@ class ShardedBprTrainer:
             per = _part(n, self.world)
             pad = torch.zeros((per,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
             pad[: x.shape[0]] = x
-            outs = [torch.empty_like(pad) for _ in range(self.world)]
-            _drain_for_gloo(pad, self.group)
-            dist.all_gather(outs, pad, group=self.group)
+            outs = _all_gather(pad, self.world, self.group)
             return torch.cat(outs)[:n]
         if self.item_mode == "dense":
             return cat(self.P, self.U), self.Q_full.clone(), self.b_full.clone()
@@ -379,8 +414,7 @@ class ShardedAprTrainer:
 
     def _sum_over_ranks(self, t):
         if self.world > 1:
-            _drain_for_gloo(t, self.group)
-            dist.all_reduce(t, group=self.group)
+            _all_reduce(t, self.group)
 
     def step(self, users, pos, neg, global_batch=None, loss=None):
         """One global minibatch step; collective (an empty local batch is allowed).  ``global_batch``:
@@ -416,9 +450,7 @@ class ShardedAprTrainer:
             return self.P.clone(), self.Q_full.clone(), self.b_full.clone()
         pad = torch.zeros((self.upr, self.d), dtype=self.P.dtype, device=self.device)
         pad[: self.P.shape[0]] = self.P
-        outs = [torch.empty_like(pad) for _ in range(self.world)]
-        _drain_for_gloo(pad, self.group)
-        dist.all_gather(outs, pad, group=self.group)
+        outs = _all_gather(pad, self.world, self.group)
         return torch.cat(outs)[: self.U], self.Q_full.clone(), self.b_full.clone()
 
 
@@ -449,10 +481,7 @@ class ShardedEvaluator:
         t = self.t
         if t.world == 1:
             return x.unsqueeze(0)
-        outs = [torch.empty_like(x) for _ in range(t.world)]
-        _drain_for_gloo(x, t.group)
-        dist.all_gather(outs, x.contiguous(), group=t.group)
-        return torch.stack(outs)
+        return torch.stack(_all_gather(x, t.world, t.group))
 
     def _evaluate_own_users(self):
         t, k = self.t, self.k
@@ -467,8 +496,7 @@ class ShardedEvaluator:
                 self.backend.fill_masked(ids, eu, k, self.train)
             sums += self.backend.metric_sums(ids, eu, k, self.test)
         if t.world > 1:
-            _drain_for_gloo(sums, t.group)
-            dist.all_reduce(sums, group=t.group)
+            _all_reduce(sums, t.group)
         return (sums / float(self.test_users.shape[0])).to(torch.float32).reshape(5, k)
 
     def evaluate(self):
@@ -489,8 +517,7 @@ class ShardedEvaluator:
                 else:
                     rows = torch.empty((n, t.d), dtype=torch.float32, device=dev)
                 if W > 1:
-                    _drain_for_gloo(rows, t.group)
-                    dist.broadcast(rows, src=o, group=t.group)
+                    _broadcast(rows, o, t.group)
                 ids, sc = self.backend.score_topk_shard(rows, t.Q, t.b, t.item_range[0], eu, k, self.train, self.mode)
                 all_ids, all_sc = self._gather_lists(ids), self._gather_lists(sc)
                 if t.rank == o:        # the owner of the users merges, fills the masked tail and scores
@@ -499,8 +526,7 @@ class ShardedEvaluator:
                         self.backend.fill_masked(mi, eu, k, self.train)
                     sums += self.backend.metric_sums(mi, eu, k, self.test)
         if W > 1:
-            _drain_for_gloo(sums, t.group)
-            dist.all_reduce(sums, group=t.group)
+            _all_reduce(sums, t.group)
         return (sums / float(self.test_users.shape[0])).to(torch.float32).reshape(5, k)
 
 
@@ -558,8 +584,7 @@ class ShardedEpochSampler:
         users, pos, neg = self.epoch(e)
         steps = torch.tensor([(self.nnz + batch_size - 1) // batch_size], dtype=torch.int64, device=t.device)
         if t.world > 1:
-            _drain_for_gloo(steps, t.group)
-            dist.all_reduce(steps, op=dist.ReduceOp.MAX, group=t.group)
+            _all_reduce(steps, t.group, op=dist.ReduceOp.MAX)
         for s in range(int(steps.item())):
             lo, hi = min(s * batch_size, self.nnz), min((s + 1) * batch_size, self.nnz)
             t.step(users[lo:hi], pos[lo:hi], neg[lo:hi])
