@@ -137,6 +137,20 @@ int tfrec_bpr_sgd_step(tfrec_ctx *ctx, float *d_P, float *d_Q, float *d_b,
                        const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg, int64_t B,
                        float lr, float reg, double *d_loss);
 
+/* tfrec_bpr_sgd_step for callers that cannot allocate.  No counterpart in the reference: it is for code under
+ * HIP graph capture, tight serving or training loops and harnesses that forbid hipMalloc.  Same arguments, same
+ * kernels, same results bit for bit; but every byte of device scratch (sorted index arrays, sort counters, staged
+ * rows, partial sums) comes from one array of 16 MiB that the library holds on each GPU it runs on until the
+ * process ends, so the call allocates and frees nothing, on the device or on the host.  A batch whose scratch
+ * does not fit (about 40,000 triples at d=64, 23,000 at d=128, 12,000 at d=256) is rejected with TFREC_EUNSUP
+ * before anything is launched.  All calls on one GPU share that GPU's array: calls that overlap there (two
+ * contexts or streams on one device) race; calls in stream order do not, and nothing needs clearing between
+ * them.  Phase timing is off during the call. */
+int tfrec_bpr_sgd_step_noalloc(tfrec_ctx *ctx, float *d_P, float *d_Q, float *d_b,
+                               int64_t U, int64_t I, int d,
+                               const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg, int64_t B,
+                               float lr, float reg, double *d_loss);
+
 /* The same step with its index work (range check, two radix sorts) taken off the critical path.
  * tfrec_batch_prepare sorts batch `slot` (0 or 1) on the context's auxiliary stream, beside
  * whatever the main stream is running; tfrec_bpr_sgd_step_prepared then runs the row passes of

@@ -50,6 +50,7 @@ SIGNATURES = {
     "tfrec_gather_rows_i32": (_int, [_p, _p, _i64, _p, _i64, _int, _p]),
     "tfrec_sort_pairs_u32": (_int, [_p, _p, _p, _p, _p, _i64, _int]),
     "tfrec_bpr_sgd_step": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _i64, _f, _f, _p]),
+    "tfrec_bpr_sgd_step_noalloc": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _i64, _f, _f, _p]),
     "tfrec_batch_prepare": (_int, [_p, _int, _i64, _i64, _p, _p, _p, _i64]),
     "tfrec_batch_prepare_many": (_int, [_p, _int, _i64, _i64, _p, _p, _p, _i64, _int]),
     "tfrec_bpr_sgd_step_prepared": (_int, [_p, _int, _p, _p, _p, _i64, _i64, _int, _f, _f, _p]),

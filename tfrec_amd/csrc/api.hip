@@ -25,6 +25,7 @@ int tfrec_ctx_enter(tfrec_ctx *ctx)
 int tfrec_ws_require(tfrec_ctx *ctx, size_t bytes)
 {
     if (bytes <= ctx->ws_bytes) return TFREC_OK;
+    TF_REQUIRE(!ctx->ws_fixed, TFREC_ENOMEM, "the fixed scratch block holds %zu bytes, %zu needed", ctx->ws_bytes, bytes);
     // grow: wait for work that may still use the old block, then replace it
     TF_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->ws) TF_HIP(hipFree(ctx->ws));
@@ -91,6 +92,12 @@ extern "C" int tfrec_ctx_create(int device, void *hip_stream, tfrec_ctx **out)
     if (e != hipSuccess) { c->d_flags = nullptr; return fail(TFREC_ENOMEM, "hipMalloc(flags)", e); }
     e = hipMemsetAsync(c->d_flags, 0, 256, c->stream);
     if (e != hipSuccess) return fail(TFREC_EHIP, "hipMemset(flags)", e);
+    if (tfrec_scratch_bind(device) != TFREC_OK) {
+        if (c->d_flags) (void)hipFree(c->d_flags);
+        if (c->own_stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+        return TFREC_EHIP;
+    }
     *out = c;
     return TFREC_OK;
 }

@@ -50,6 +50,7 @@ struct tfrec_batch_slot {
     uint32_t kmask = 0xffffffffu;            // key bits below the batch number
     uint32_t *keys = nullptr, *vals = nullptr;   // [3B] sorted: user side [0,B), item side [B,3B)
     uint2 *pair = nullptr;                   // [K*B] (i, j) of every triple
+    const int32_t *users_raw = nullptr, *pos_raw = nullptr, *neg_raw = nullptr;   // the caller's index arrays [K*B]
     hipEvent_t ready = nullptr;              // recorded on the auxiliary stream after preparation
     hipEvent_t released = nullptr;           // recorded on the main stream after the step that consumed the slot
     bool has_released = false;
@@ -63,6 +64,7 @@ struct tfrec_ctx {
     char *ws = nullptr;          // device workspace
     size_t ws_bytes = 0;
     size_t ws_used = 0;          // bump pointer, reset at the start of every entry point
+    bool ws_fixed = false;       // the workspace is a borrowed block of fixed size: never grown, never freed
     uint32_t *d_flags = nullptr; // sticky device-side error flags (4 bytes, separate allocation)
     void *h_pinned = nullptr;    // small pinned staging buffer for host outputs
     size_t h_pinned_bytes = 0;
@@ -82,6 +84,9 @@ struct tfrec_ctx {
 void tfrec_mark(tfrec_ctx *ctx, const char *name);
 void tfrec_marks_reset(tfrec_ctx *ctx);
 
+// Looks up this device's copy of the file-scope scratch array of the no-allocation step (train.hip); called by
+// tfrec_ctx_create with the device current.
+int tfrec_scratch_bind(int device);
 // Makes ctx's device current for the calling thread.
 int tfrec_ctx_enter(tfrec_ctx *ctx);
 // Ensures the workspace holds at least `bytes` (may reallocate: previous carve-outs die).

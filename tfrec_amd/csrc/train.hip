@@ -16,6 +16,8 @@
 // parameters although both tables are updated in place.
 #include "seg_pass.hpp"
 
+#include <atomic>
+
 // ------------------------------------------------------------------------------------------
 // keys
 // ------------------------------------------------------------------------------------------
@@ -64,6 +66,7 @@ struct BprParams {
     float *stage;        // [B, d] pre-step P[u] of every triple
     float *sbuf;         // [B]    s = sigma(-(x + 1e-7)) of every triple
     const uint2 *pair;   // [B]    (i, j) of every triple, range-checked
+    const int32_t *users;   // [B] the caller's user ids (clamped on use)
     uint32_t U;
     int d, nchunk;
     float lr, reg;
@@ -633,6 +636,7 @@ static int slot_prepare(tfrec_ctx *ctx, tfrec_batch_slot &sl, hipStream_t stream
     TF_HIP(hipGetLastError());
     TF_TRY(tfrec_sort_pairs(sort_tmp, sort_bytes, keys_in, sl.keys, vals_in, sl.vals, (size_t)3 * n, total_bits, stream));
     sl.B = B; sl.U = U; sl.I = I; sl.K = K; sl.next_k = 0; sl.apr_pending = 0;
+    sl.users_raw = users; sl.pos_raw = pos; sl.neg_raw = neg;
     sl.kmask = kb >= 32 ? 0xffffffffu : ((1u << kb) - 1u);
     return TFREC_OK;
 }
@@ -746,7 +750,8 @@ static int bpr_passes(tfrec_ctx *ctx, const tfrec_batch_slot &sl, float *d_P, fl
     TF_REQUIRE(pick_cfg(d, all_aligned16({d_P, d_Q}), &cfg), TFREC_EUNSUP, "factor size d=%d is not supported (max 256)", d);
     StepWs w;
     TF_TRY(step_ws_carve(ctx, B, d, cfg, &w));
-    BprParams a{d_P, d_Q, d_b, d_gQ ? d_gQ : d_Q, d_gb ? d_gb : d_b, w.stage, w.sbuf, sl.pair + B * k0, (uint32_t)U, d, d / cfg.vec, lr, reg, sl.kmask};
+    BprParams a{d_P, d_Q, d_b, d_gQ ? d_gQ : d_Q, d_gb ? d_gb : d_b, w.stage, w.sbuf, sl.pair + B * k0, sl.users_raw + B * k0,
+                (uint32_t)U, d, d / cfg.vec, lr, reg, sl.kmask};
     const bool want_loss = d_loss != nullptr;
     return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC, bool FULL>() -> int {
         if (want_loss) {
@@ -839,6 +844,73 @@ extern "C" int tfrec_bpr_sgd_step(tfrec_ctx *ctx, float *d_P, float *d_Q, float 
     TF_TRY(slot_prepare(ctx, sl, ctx->stream, d_users, d_pos, d_neg, B, U, I));
     tfrec_mark(ctx, "index");
     return bpr_passes(ctx, sl, d_P, d_Q, d_b, U, d, lr, reg, d_loss);
+}
+
+// ------------------------------------------------------------------------------------------
+// The step for callers that cannot allocate (code under HIP graph capture, tight serving or
+// training loops, harnesses that forbid hipMalloc): every byte of device scratch -- sorted index
+// arrays, sort counters, staged rows, partial sums -- lives in a file-scope device array instead of
+// the context's growable workspace.  Each GPU holds its own copy of the array at its own address;
+// host code reaches it only through the address hipGetSymbolAddress returned for that device.
+// ------------------------------------------------------------------------------------------
+static constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)16 << 20;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+static constexpr int NOALLOC_MAX_DEVICES = 64;
+static std::atomic<void *> g_scratch_ptr[NOALLOC_MAX_DEVICES];     // per device: where `scratch` lives on it
+
+int tfrec_scratch_bind(int device)
+{
+    if (device < 0 || device >= NOALLOC_MAX_DEVICES) return TFREC_OK;     // the no-allocation step is not offered there
+    if (g_scratch_ptr[device].load(std::memory_order_acquire)) return TFREC_OK;
+    void *p = nullptr;
+    TF_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    TF_REQUIRE(p != nullptr, TFREC_EHIP, "hipGetSymbolAddress returned no address for the scratch array");
+    g_scratch_ptr[device].store(p, std::memory_order_release);
+    return TFREC_OK;
+}
+
+extern "C" int tfrec_bpr_sgd_step_noalloc(tfrec_ctx *ctx, float *d_P, float *d_Q, float *d_b, int64_t U, int64_t I, int d,
+                                          const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg, int64_t B, float lr,
+                                          float reg, double *d_loss)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_TRY(check_step_args(d_P, d_Q, d_b, U, I, d, d_users, d_pos, d_neg, B));
+    if (B == 0) {
+        if (d_loss) TF_HIP(hipMemsetAsync(d_loss, 0, 2 * sizeof(double), ctx->stream));
+        return TFREC_OK;
+    }
+    TF_REQUIRE(ctx->device >= 0 && ctx->device < NOALLOC_MAX_DEVICES, TFREC_EUNSUP, "the no-allocation step serves devices 0..%d",
+               NOALLOC_MAX_DEVICES - 1);
+    char *base = (char *)g_scratch_ptr[ctx->device].load(std::memory_order_acquire);
+    TF_REQUIRE(base != nullptr, TFREC_EHIP, "the scratch array of device %d was never looked up", ctx->device);
+    RowCfg cfg;
+    TF_REQUIRE(pick_cfg(d, all_aligned16({d_P, d_Q}), &cfg), TFREC_EUNSUP, "factor size d=%d is not supported (max 256)", d);
+    size_t sort_bytes = 0;
+    const size_t slot_need = tf_align(slot_bytes(B, &sort_bytes)), ws_need = step_ws_bytes(B, d, cfg);
+    TF_REQUIRE(slot_need + ws_need <= NOALLOC_SCRATCH_BYTES, TFREC_EUNSUP,
+               "a batch of %lld triples at d=%d needs %zu bytes of scratch; the no-allocation step holds %zu (use tfrec_bpr_sgd_step)",
+               (long long)B, d, slot_need + ws_need, NOALLOC_SCRATCH_BYTES);
+    // the index arrays at the front of the array, the row passes' workspace behind them; nothing here has to start at
+    // zero (every word a kernel reads was written earlier in the same call)
+    tfrec_batch_slot sl;
+    sl.mem = base;
+    sl.bytes = slot_need;
+    char *const saved_ws = ctx->ws;
+    const size_t saved_bytes = ctx->ws_bytes;
+    const bool saved_fixed = ctx->ws_fixed, saved_profile = ctx->profile;
+    ctx->ws = base + slot_need;
+    ctx->ws_bytes = NOALLOC_SCRATCH_BYTES - slot_need;
+    ctx->ws_used = 0;
+    ctx->ws_fixed = true;
+    ctx->profile = false;              // phase marks create events on first use
+    int rc = slot_prepare(ctx, sl, ctx->stream, d_users, d_pos, d_neg, B, U, I);
+    if (rc == TFREC_OK) rc = bpr_passes(ctx, sl, d_P, d_Q, d_b, U, d, lr, reg, d_loss);
+    ctx->ws = saved_ws;
+    ctx->ws_bytes = saved_bytes;
+    ctx->ws_used = 0;
+    ctx->ws_fixed = saved_fixed;
+    ctx->profile = saved_profile;
+    return rc;
 }
 
 extern "C" int tfrec_batch_prepare(tfrec_ctx *ctx, int slot, int64_t U, int64_t I, const int32_t *d_users, const int32_t *d_pos,

@@ -220,6 +220,15 @@ class Device:
         _lib.check(self.lib.tfrec_bpr_sgd_step(self.h, _ptr(P), _ptr(Q), _ptr(b), U, I, d, _ptr(users), _ptr(pos), _ptr(neg), B,
                                                float(lr), float(reg), _ptr(loss)))
 
+    def bpr_sgd_step_noalloc(self, P, Q, b, users, pos, neg, lr, reg, loss=None):
+        """``bpr_sgd_step`` for callers that cannot allocate: all device scratch comes from a fixed array inside
+        the library (16 MiB per GPU); larger batches raise NotImplementedError.  Calls that overlap on one GPU race."""
+        U, d = _shape(P)
+        I = _shape(Q)[0]
+        B = _shape(users)[0]
+        _lib.check(self.lib.tfrec_bpr_sgd_step_noalloc(self.h, _ptr(P), _ptr(Q), _ptr(b), U, I, d, _ptr(users), _ptr(pos), _ptr(neg),
+                                                       B, float(lr), float(reg), _ptr(loss)))
+
     def prepare_batch(self, slot, U, I, users, pos, neg):
         """Sorts a batch on the auxiliary stream (overlaps the row passes of the running step)."""
         B = _shape(users)[0]
