@@ -289,6 +289,7 @@ def main():
                     help="multi-GPU item table: replicated with one all-reduce of gradient sums per step, or sharded with all-to-all lookups")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend for N>1 (gloo: testing only)")
     ap.add_argument("--single-device", action="store_true", help="testing: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--plain-table", action="store_true", help="single GPU: plain user table (pre-step rows staged per triple) instead of the versioned one")
     ap.add_argument("--extras", action="store_true", help="also time the reference batch size (512 triples per step)")
     args = ap.parse_args()
 
@@ -330,6 +331,9 @@ def main():
             pos = zipf_items(I, n_batches * B, gen, cuda)
             neg = torch.randint(0, I, (n_batches * B,), device=cuda, generator=gen, dtype=torch.int32)
             dev.reserve(B, d)
+            # the user table is versioned (tfrec_utable): steps need not stage the pre-step user rows for their
+            # item half; P itself is complete again after ut.flatten()
+            ut = dev.user_table(P) if not args.plain_table else None
 
             def batch(s):
                 o = (s % n_batches) * B
@@ -353,7 +357,10 @@ def main():
                 g, r = divmod(k, K)
                 if r == 0:
                     dev.prepare_batches((g + 1) & 1, U, I, *group(g + 1), K)
-                dev.bpr_sgd_step_prepared(g & 1, P, Q, b, lr, reg)
+                if ut is not None:
+                    dev.bpr_sgd_step_prepared_v(g & 1, ut, Q, b, lr, reg)
+                else:
+                    dev.bpr_sgd_step_prepared(g & 1, P, Q, b, lr, reg)
                 state["next"] = k + 1
             trainer = None
         else:
@@ -505,10 +512,15 @@ def main():
             dev.set_profiling(True)
             acc, reps = {}, 10
             for s in range(reps):
-                dev.bpr_sgd_step(P, Q, b, *batch(s), lr, reg)
+                if ut is not None:
+                    dev.bpr_sgd_step_v(ut, Q, b, *batch(s), lr, reg)
+                else:
+                    dev.bpr_sgd_step(P, Q, b, *batch(s), lr, reg)
                 for name, t in dev.phase_times():
                     acc[name] = acc.get(name, 0.0) + t / reps
             dev.set_profiling(False)
+            if ut is not None:
+                ut.flatten()            # P is complete again for what follows
             step_ms = sum(acc.values())
             dom = max(acc, key=acc.get)
             achieved = B * alg_bytes_per_triple / (dev_ms / args.steps * 1e-3) / 1e9
@@ -517,7 +529,8 @@ def main():
                 "traffic": pmc_traffic(B, d),
                 "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
                                   "committed with the profiles), not measured in this run",
-                "kernel": "one BPR step = build_keys + radix sort + seg_tile/seg_fixup (user side) + seg_tile/seg_fixup (item side)",
+                "kernel": "one BPR step = build_keys + radix sort + seg_tile/seg_fixup (user side) + seg_tile/seg_fixup (item side)"
+                          + (" + version flip, on a versioned user table" if ut is not None else ""),
                 "algorithmic_bytes_per_triple": alg_bytes_per_triple,
                 "device_ms_per_step": dev_ms / args.steps,
                 "phases_ms": acc, "dominant_phase": dom,

@@ -168,6 +168,34 @@ int tfrec_batch_prepare_many(tfrec_ctx *ctx, int slot, int64_t U, int64_t I,
 int tfrec_bpr_sgd_step_prepared(tfrec_ctx *ctx, int slot, float *d_P, float *d_Q, float *d_b,
                                 int64_t U, int64_t I, int d, float lr, float reg, double *d_loss);
 
+/* ---- versioned user table -------------------------------------------------------------------
+ * The steps above update P in place, yet the item half of a step needs the PRE-step user rows
+ * (model/BPR.py:47-48: every gradient at the pre-step parameters), so they stage a copy of every
+ * triple's user row: one row written and two read per triple, 45 % of the bytes a step moves.  A
+ * tfrec_utable avoids the copies: it pairs the caller's table d_P with a second row buffer and one
+ * version byte per user (both owned by the library).  A row's current value is in d_P when its byte is
+ * 0, in the second buffer when it is 1; a step reads the current rows, writes the updated rows into
+ * the other buffer, lets the item half read the old rows where they still are, and flips the bytes of
+ * the batch's users at the end.  Same arithmetic in the same order: after tfrec_utable_flatten d_P holds
+ * bit for bit what the plain steps leave there.  No counterpart in the reference (TensorFlow keeps its
+ * variables behind the session too, run_model.py:14-16).
+ *   tfrec_utable_create   wraps d_P [U, d] (caller-owned; its current contents are the table)
+ *   tfrec_utable_flatten  copies the rows that live in the second buffer back: d_P is then complete
+ *                         and current again (stream-ordered).  REQUIRED before anything else reads d_P
+ *                         (evaluation, prediction, DNS selection, checkpoints, the plain steps).
+ *   tfrec_utable_destroy  flattens, waits, frees.
+ * The *_v steps take the table in place of (d_P, U, d) and are otherwise the entry points of the same
+ * name without the suffix. */
+typedef struct tfrec_utable tfrec_utable;
+int tfrec_utable_create(tfrec_ctx *ctx, float *d_P, int64_t U, int d, tfrec_utable **out);
+int tfrec_utable_flatten(tfrec_ctx *ctx, tfrec_utable *t);
+int tfrec_utable_destroy(tfrec_ctx *ctx, tfrec_utable *t);
+int tfrec_bpr_sgd_step_v(tfrec_ctx *ctx, tfrec_utable *t, float *d_Q, float *d_b, int64_t I,
+                         const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg, int64_t B,
+                         float lr, float reg, double *d_loss);
+int tfrec_bpr_sgd_step_prepared_v(tfrec_ctx *ctx, int slot, tfrec_utable *t, float *d_Q, float *d_b, int64_t I,
+                                  float lr, float reg, double *d_loss);
+
 /* The two halves of a step on row-sharded tables (no counterpart in the reference, which is a
  * single process, run_model.py:14-16; the arithmetic is that of model/BPR.py:36-48).
  * tfrec_bpr_grad_step: like tfrec_bpr_sgd_step on P (complete update: the caller routes every
@@ -196,6 +224,10 @@ int tfrec_bpr_dense_grad_step(tfrec_ctx *ctx, int slot, float *d_P, const float 
                               int64_t U, int64_t I, int d,
                               const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg, int64_t B,
                               float lr, float reg, double *d_loss);
+/* The same on a versioned user table (see tfrec_utable above). */
+int tfrec_bpr_dense_grad_step_v(tfrec_ctx *ctx, int slot, tfrec_utable *t, const float *d_Q, const float *d_b, float *d_G,
+                                int64_t I, const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg, int64_t B,
+                                float lr, float reg, double *d_loss);
 /* y[i] = fma(alpha, x[i], y[i]) for i < n: the plain SGD update (model/BPR.py:48) of a replicated
  * table from a summed gradient table, alpha = -learning rate. */
 int tfrec_axpy(tfrec_ctx *ctx, float *d_y, const float *d_x, float alpha, int64_t n);

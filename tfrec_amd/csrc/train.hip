@@ -62,6 +62,12 @@ __global__ __launch_bounds__(256) void build_keys_kernel(const int32_t *__restri
 
 struct BprParams {
     float *P, *Q, *b;
+    // Versioned user table (tfrec_utable): row u lives in P2 when ver[u] is set, else in P.  A step reads the
+    // current copy of a row and writes the updated row into the other buffer; the item pass, which needs the
+    // pre-step rows, still finds them where ver[] says; the version bytes of the batch's users are flipped when
+    // both passes are done.  Null in the plain layout.
+    float *P2;
+    uint8_t *ver;
     float *gQ, *gb;      // where the item pass leaves gradient sums when it does not apply them (may alias Q, b)
     float *stage;        // [B, d] pre-step P[u] of every triple
     float *sbuf;         // [B]    s = sigma(-(x + 1e-7)) of every triple
@@ -73,7 +79,8 @@ struct BprParams {
     uint32_t kmask;      // sorted keys carry a batch number above these bits when several batches were sorted together
 };
 
-template <int LPR_, int NCH_, int VEC_, bool FULL_, bool LOSS>
+// VER: the user table is versioned (see BprParams): no pre-step rows are staged for the item pass.
+template <int LPR_, int NCH_, int VEC_, bool FULL_, bool LOSS, bool VER = false>
 struct BprUserPol {
     enum { LPR = LPR_, NCH = NCH_, VEC = VEC_, DEPTH = TF_DEPTH_USER };
     using RowT = Row<LPR_, NCH_, VEC_>;
@@ -83,15 +90,18 @@ struct BprUserPol {
     struct Occ { RowT p, qi, qj; float bi, bj; };
     struct Seg { RowT p; };
 
+    // .y = occurrence id; its top bit carries the row's version (occurrence ids stay below 2^30)
     __device__ __forceinline__ uint4 entry(uint32_t key, uint32_t val, int64_t) const
     {
         const uint2 ij = a.pair[val];
+        if constexpr (VER) val |= (uint32_t)a.ver[key & a.kmask] << 31;
         return make_uint4(key, val, ij.x, ij.y);
     }
     __device__ __forceinline__ Occ load_occ(uint4 en, int gl) const
     {
         Occ o;
-        o.p = RowT::load(a.P + (size_t)(en.x & a.kmask) * DM::d(a.d), gl, DM::nchunk(a.nchunk));
+        const float *src = (VER && (en.y >> 31)) ? a.P2 : a.P;
+        o.p = RowT::load(src + (size_t)(en.x & a.kmask) * DM::d(a.d), gl, DM::nchunk(a.nchunk));
         o.qi = RowT::load(a.Q + (size_t)en.z * DM::d(a.d), gl, DM::nchunk(a.nchunk));
         o.qj = RowT::load(a.Q + (size_t)en.w * DM::d(a.d), gl, DM::nchunk(a.nchunk));
         o.bi = a.b[en.z];
@@ -108,8 +118,14 @@ struct BprUserPol {
         acc.v.fma(s, diff);          // user gradient is  -sum s*(q_i - q_j) + n*reg*p
         acc.cnt += 1;
         seg.p = o.p;
-        o.p.store(a.stage + (size_t)en.y * DM::d(a.d), gl, DM::nchunk(a.nchunk));
-        if (gl == 0) a.sbuf[en.y] = s;
+        const uint32_t t = VER ? (en.y & 0x7fffffffu) : en.y;
+        if constexpr (VER) {
+            // what the item pass needs from this triple in one 8-byte record: s, and where the pre-step user row is
+            if (gl == 0) reinterpret_cast<uint2 *>(a.sbuf)[t] = make_uint2(__float_as_uint(s), (en.x & a.kmask) | (en.y & 0x80000000u));
+        } else {
+            o.p.store(a.stage + (size_t)t * DM::d(a.d), gl, DM::nchunk(a.nchunk));
+            if (gl == 0) a.sbuf[t] = s;
+        }
         if constexpr (LOSS) {
             float r = o.p.dot_partial(o.p) + o.qi.dot_partial(o.qi) + o.qj.dot_partial(o.qj);
             if (gl == 0) {
@@ -121,11 +137,14 @@ struct BprUserPol {
     }
     __device__ __forceinline__ void apply(uint32_t key, const Seg *seg, const Acc<RowT> &acc, int gl) const
     {
-        float *row = a.P + (size_t)(key & a.kmask) * DM::d(a.d);
-        const RowT p = seg ? seg->p : RowT::load(row, gl, DM::nchunk(a.nchunk));
+        const size_t off = (size_t)(key & a.kmask) * DM::d(a.d);
+        const bool v = VER && a.ver[key & a.kmask] != 0;        // where the current row is; the new one goes to the other buffer
+        const float *src = v ? a.P2 : a.P;
+        float *dst = VER ? (v ? a.P : a.P2) : a.P;
+        const RowT p = seg ? seg->p : RowT::load(src + off, gl, DM::nchunk(a.nchunk));
         const float nreg = (float)acc.cnt * a.reg, lr = a.lr;
         const RowT out = p.map2(acc.v, [=](float pv, float av) { return fmaf(-lr, fmaf(nreg, pv, -av), pv); });
-        out.store(row, gl, DM::nchunk(a.nchunk));
+        out.store(dst + off, gl, DM::nchunk(a.nchunk));
     }
 };
 
@@ -133,7 +152,7 @@ struct BprUserPol {
 // distinct item in row `it` of gQ / entry `it` of gb instead.  Those are either Q, b themselves
 // (the tables then hold fetched copies of rows owned by other GPUs, and the sums travel back to
 // the owners) or a zeroed table of the shape of Q, b that is then summed over the GPUs.
-template <int LPR_, int NCH_, int VEC_, bool FULL_, bool GRAD = false>
+template <int LPR_, int NCH_, int VEC_, bool FULL_, bool GRAD = false, bool VER = false>
 struct BprItemPol {
     enum { LPR = LPR_, NCH = NCH_, VEC = VEC_, DEPTH = TF_DEPTH_ITEM };
     using RowT = Row<LPR_, NCH_, VEC_>;
@@ -143,13 +162,26 @@ struct BprItemPol {
     struct Occ { RowT p; float s; };
     struct Seg { RowT q; float bk; };
 
-    __device__ __forceinline__ uint4 entry(uint32_t key, uint32_t val, int64_t) const { return make_uint4(key, val, 0, 0); }
+    // versioned user table: the triple's record from the user pass rides in the entry: .z = user | version << 31, .w = s
+    __device__ __forceinline__ uint4 entry(uint32_t key, uint32_t val, int64_t) const
+    {
+        if constexpr (VER) {
+            const uint2 su = reinterpret_cast<const uint2 *>(a.sbuf)[val >> 1];
+            return make_uint4(key, val, su.y, su.x);
+        }
+        return make_uint4(key, val, 0, 0);
+    }
     __device__ __forceinline__ Occ load_occ(uint4 en, int gl) const
     {
         const uint32_t t = en.y >> 1;
         Occ o;
-        o.p = RowT::load(a.stage + (size_t)t * DM::d(a.d), gl, DM::nchunk(a.nchunk));
-        o.s = a.sbuf[t];
+        if constexpr (VER) {
+            o.p = RowT::load(((en.z >> 31) ? a.P2 : a.P) + (size_t)(en.z & 0x7fffffffu) * DM::d(a.d), gl, DM::nchunk(a.nchunk));
+            o.s = __uint_as_float(en.w);
+        } else {
+            o.p = RowT::load(a.stage + (size_t)t * DM::d(a.d), gl, DM::nchunk(a.nchunk));
+            o.s = a.sbuf[t];
+        }
         return o;
     }
     __device__ __forceinline__ Seg load_seg(uint32_t key, int gl) const
@@ -658,7 +690,7 @@ static size_t step_ws_bytes(int64_t B, int d, const RowCfg &c)
     const size_t rowf = (size_t)c.lpr * c.nch * c.vec;
     size_t s = 0;
     s += tf_align(sizeof(float) * (size_t)B * d);          // stage
-    s += tf_align(sizeof(float) * B);                      // sbuf
+    s += tf_align(sizeof(float) * 2 * B);                  // sbuf (8-byte records on a versioned user table)
     const int64_t slots = 2 * tiles + tiles / (256 / c.lpr) + 2;   // two per tile + one per workgroup
     s += tf_align(sizeof(float) * slots * rowf);           // partial rows
     s += tf_align(sizeof(float4) * slots);
@@ -683,14 +715,14 @@ size_t tfrec_step_need_bytes(int64_t B, int d)
     return best;
 }
 
-static int step_ws_carve(tfrec_ctx *ctx, int64_t B, int d, const RowCfg &c, StepWs *w)
+static int step_ws_carve(tfrec_ctx *ctx, int64_t B, int d, const RowCfg &c, StepWs *w, bool with_stage = true)
 {
     TF_TRY(tfrec_ws_require(ctx, ctx->ws_used + step_ws_bytes(B, d, c)));
     const int CH = c.lpr > 32 ? c.lpr : 32, GPB = 256 / c.lpr;
     const int64_t tiles = (2 * B + CH - 1) / CH + 1;
     const size_t rowf = (size_t)c.lpr * c.nch * c.vec;
-    w->stage = (float *)tfrec_ws_take(ctx, sizeof(float) * (size_t)B * d);
-    w->sbuf = (float *)tfrec_ws_take(ctx, sizeof(float) * B);
+    w->stage = with_stage ? (float *)tfrec_ws_take(ctx, sizeof(float) * (size_t)B * d) : nullptr;
+    w->sbuf = (float *)tfrec_ws_take(ctx, sizeof(float) * 2 * B);
     const int64_t slots = 2 * tiles + tiles / GPB + 2;
     w->part_rows = (float *)tfrec_ws_take(ctx, sizeof(float) * slots * rowf);
     w->part_sc = (float4 *)tfrec_ws_take(ctx, sizeof(float4) * slots);
@@ -739,36 +771,130 @@ static int run_pass(tfrec_ctx *ctx, const Pol &pol, const StepWs &w, const uint3
     return TFREC_OK;
 }
 
-// the row passes of one BPR step over an already sorted batch
+// ------------------------------------------------------------------------------------------
+// versioned user table
+// ------------------------------------------------------------------------------------------
+struct tfrec_utable {
+    float *P = nullptr;       // the caller's table [U, d]: the rows whose version byte is 0
+    float *P2 = nullptr;      // second row buffer [U, d] (owned): the rows whose version byte is 1
+    uint8_t *ver = nullptr;   // [U] (owned)
+    int64_t U = 0;
+    int d = 0, device = 0;
+};
+
+// the batch's distinct users (heads of the sorted user keys) now live in the other buffer
+__global__ __launch_bounds__(256) void utable_flip_kernel(const uint32_t *__restrict__ keys, int64_t n, uint32_t kmask,
+                                                          uint8_t *__restrict__ ver)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t k = keys[t];
+    if (t == 0 || keys[t - 1] != k) ver[k & kmask] ^= 1;
+}
+
+// one wave per row: rows that live in the second buffer are copied back, their version byte is cleared
+__global__ __launch_bounds__(256) void utable_flatten_kernel(float *__restrict__ P, const float *__restrict__ P2, uint8_t *__restrict__ ver,
+                                                             int64_t U, int d)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < U; r += stride) {
+        if (ver[r] == 0) continue;                      // wave-uniform
+        for (int f = lane; f < d; f += 64) P[(size_t)r * d + f] = P2[(size_t)r * d + f];
+        if (lane == 0) ver[r] = 0;                      // (every lane of the wave has read it by now: one instruction stream)
+    }
+}
+
+// the row passes of one BPR step over an already sorted batch; ut: the versioned user table, or null for the
+// plain layout (the pre-step user rows are then staged for the item pass)
 static int bpr_passes(tfrec_ctx *ctx, const tfrec_batch_slot &sl, float *d_P, float *d_Q, float *d_b, int64_t U, int d,
-                      float lr, float reg, double *d_loss, bool item_grad_only = false, float *d_gQ = nullptr, float *d_gb = nullptr)
+                      float lr, float reg, double *d_loss, bool item_grad_only = false, float *d_gQ = nullptr, float *d_gb = nullptr,
+                      const tfrec_utable *ut = nullptr)
 {
     const int64_t B = sl.B;
     const int64_t k0 = sl.next_k;                 // which of the slot's batches this step consumes
     const uint32_t *keys = sl.keys + 3 * B * k0, *vals = sl.vals + 3 * B * k0;
     RowCfg cfg;
-    TF_REQUIRE(pick_cfg(d, all_aligned16({d_P, d_Q}), &cfg), TFREC_EUNSUP, "factor size d=%d is not supported (max 256)", d);
+    TF_REQUIRE(pick_cfg(d, all_aligned16({d_P, d_Q, ut ? ut->P2 : nullptr}), &cfg), TFREC_EUNSUP, "factor size d=%d is not supported (max 256)", d);
     StepWs w;
-    TF_TRY(step_ws_carve(ctx, B, d, cfg, &w));
-    BprParams a{d_P, d_Q, d_b, d_gQ ? d_gQ : d_Q, d_gb ? d_gb : d_b, w.stage, w.sbuf, sl.pair + B * k0, sl.users_raw + B * k0,
-                (uint32_t)U, d, d / cfg.vec, lr, reg, sl.kmask};
+    TF_TRY(step_ws_carve(ctx, B, d, cfg, &w, ut == nullptr));
+    BprParams a{d_P, d_Q, d_b, ut ? ut->P2 : nullptr, ut ? ut->ver : nullptr, d_gQ ? d_gQ : d_Q, d_gb ? d_gb : d_b, w.stage, w.sbuf,
+                sl.pair + B * k0, sl.users_raw + B * k0, (uint32_t)U, d, d / cfg.vec, lr, reg, sl.kmask};
     const bool want_loss = d_loss != nullptr;
-    return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC, bool FULL>() -> int {
+    auto passes = [&]<int LPR, int NCH, int VEC, bool FULL, bool VER>() -> int {
         if (want_loss) {
-            TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, FULL, true>{a}, w, keys, vals, 0, B, w.n_tiles_u, w.blocks_u, true,
+            TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, FULL, true, VER>{a}, w, keys, vals, 0, B, w.n_tiles_u, w.blocks_u, true,
                             "user_tile", "user_fixup"));
             loss_finalize_kernel<2><<<1, 256, 0, ctx->stream>>>(w.loss_part, w.blocks_u, d_loss);
             TF_HIP(hipGetLastError());
         } else {
-            TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, FULL, false>{a}, w, keys, vals, 0, B, w.n_tiles_u, w.blocks_u, false,
+            TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, FULL, false, VER>{a}, w, keys, vals, 0, B, w.n_tiles_u, w.blocks_u, false,
                             "user_tile", "user_fixup"));
         }
         if (item_grad_only)
-            return run_pass(ctx, BprItemPol<LPR, NCH, VEC, FULL, true>{a}, w, keys, vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false,
+            return run_pass(ctx, BprItemPol<LPR, NCH, VEC, FULL, true, VER>{a}, w, keys, vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false,
                             "item_tile", "item_fixup");
-        return run_pass(ctx, BprItemPol<LPR, NCH, VEC, FULL>{a}, w, keys, vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false, "item_tile",
-                        "item_fixup");
-    });
+        return run_pass(ctx, BprItemPol<LPR, NCH, VEC, FULL, false, VER>{a}, w, keys, vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false,
+                        "item_tile", "item_fixup");
+    };
+    if (!ut) return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC, bool FULL>() -> int { return passes.template operator()<LPR, NCH, VEC, FULL, false>(); });
+    TF_TRY(dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC, bool FULL>() -> int { return passes.template operator()<LPR, NCH, VEC, FULL, true>(); }));
+    utable_flip_kernel<<<(unsigned)((B + 255) / 256), 256, 0, ctx->stream>>>(keys, B, sl.kmask, ut->ver);
+    TF_HIP(hipGetLastError());
+    tfrec_mark(ctx, "version_flip");
+    return TFREC_OK;
+}
+
+static int check_utable(tfrec_ctx *ctx, const tfrec_utable *t)
+{
+    TF_REQUIRE(t != nullptr && t->P && t->P2 && t->ver, TFREC_EINVAL, "null or destroyed user table");
+    TF_REQUIRE(t->device == ctx->device, TFREC_EINVAL, "the user table lives on device %d, the context on device %d", t->device, ctx->device);
+    return TFREC_OK;
+}
+
+extern "C" int tfrec_utable_create(tfrec_ctx *ctx, float *d_P, int64_t U, int d, tfrec_utable **out)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_REQUIRE(out != nullptr && d_P != nullptr, TFREC_EINVAL, "null pointer");
+    TF_REQUIRE(U > 0 && U < (1ll << 31) && d > 0 && d <= 256, TFREC_EINVAL, "bad table shape U=%lld d=%d", (long long)U, d);
+    tfrec_utable *t = new (std::nothrow) tfrec_utable();
+    TF_REQUIRE(t != nullptr, TFREC_ENOMEM, "host allocation failed");
+    t->P = d_P; t->U = U; t->d = d; t->device = ctx->device;
+    hipError_t e = hipMalloc((void **)&t->P2, sizeof(float) * (size_t)U * d);
+    if (e == hipSuccess) e = hipMalloc((void **)&t->ver, (size_t)U);
+    if (e == hipSuccess) e = hipMemsetAsync(t->ver, 0, (size_t)U, ctx->stream);
+    if (e != hipSuccess) {
+        tfrec_set_error("allocation of the second row buffer (%zu bytes) failed: %s", sizeof(float) * (size_t)U * d, hipGetErrorString(e));
+        if (t->P2) (void)hipFree(t->P2);
+        if (t->ver) (void)hipFree(t->ver);
+        delete t;
+        return TFREC_ENOMEM;
+    }
+    *out = t;
+    return TFREC_OK;
+}
+
+extern "C" int tfrec_utable_flatten(tfrec_ctx *ctx, tfrec_utable *t)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_TRY(check_utable(ctx, t));
+    const int64_t blocks = (t->U + 3) / 4;
+    utable_flatten_kernel<<<(unsigned)(blocks < 65536 ? blocks : 65536), 256, 0, ctx->stream>>>(t->P, t->P2, t->ver, t->U, t->d);
+    TF_HIP(hipGetLastError());
+    return TFREC_OK;
+}
+
+extern "C" int tfrec_utable_destroy(tfrec_ctx *ctx, tfrec_utable *t)
+{
+    if (!t) return TFREC_OK;
+    TF_TRY(tfrec_utable_flatten(ctx, t));
+    TF_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->aux_stream) TF_HIP(hipStreamSynchronize(ctx->aux_stream));
+    (void)hipFree(t->P2);
+    (void)hipFree(t->ver);
+    t->P2 = nullptr; t->ver = nullptr; t->P = nullptr;
+    delete t;
+    return TFREC_OK;
 }
 
 extern "C" int tfrec_bpr_grad_step(tfrec_ctx *ctx, float *d_P, float *d_Qc, float *d_bc, int64_t U, int64_t Ic, int d,
@@ -828,11 +954,10 @@ extern "C" int tfrec_rows_sgd_apply(tfrec_ctx *ctx, float *d_Q, float *d_b, int6
     });
 }
 
-extern "C" int tfrec_bpr_sgd_step(tfrec_ctx *ctx, float *d_P, float *d_Q, float *d_b, int64_t U, int64_t I, int d,
-                                  const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg, int64_t B, float lr,
-                                  float reg, double *d_loss)
+static int sgd_step_impl(tfrec_ctx *ctx, float *d_P, float *d_Q, float *d_b, int64_t U, int64_t I, int d, const int32_t *d_users,
+                         const int32_t *d_pos, const int32_t *d_neg, int64_t B, float lr, float reg, double *d_loss,
+                         const tfrec_utable *ut)
 {
-    TF_TRY(tfrec_ctx_enter(ctx));
     TF_TRY(check_step_args(d_P, d_Q, d_b, U, I, d, d_users, d_pos, d_neg, B));
     if (B == 0) {
         if (d_loss) TF_HIP(hipMemsetAsync(d_loss, 0, 2 * sizeof(double), ctx->stream));
@@ -843,7 +968,23 @@ extern "C" int tfrec_bpr_sgd_step(tfrec_ctx *ctx, float *d_P, float *d_Q, float 
     tfrec_batch_slot &sl = ctx->slots[2];      // private slot of the unpipelined entry points, main stream only
     TF_TRY(slot_prepare(ctx, sl, ctx->stream, d_users, d_pos, d_neg, B, U, I));
     tfrec_mark(ctx, "index");
-    return bpr_passes(ctx, sl, d_P, d_Q, d_b, U, d, lr, reg, d_loss);
+    return bpr_passes(ctx, sl, d_P, d_Q, d_b, U, d, lr, reg, d_loss, false, nullptr, nullptr, ut);
+}
+
+extern "C" int tfrec_bpr_sgd_step(tfrec_ctx *ctx, float *d_P, float *d_Q, float *d_b, int64_t U, int64_t I, int d,
+                                  const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg, int64_t B, float lr,
+                                  float reg, double *d_loss)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    return sgd_step_impl(ctx, d_P, d_Q, d_b, U, I, d, d_users, d_pos, d_neg, B, lr, reg, d_loss, nullptr);
+}
+
+extern "C" int tfrec_bpr_sgd_step_v(tfrec_ctx *ctx, tfrec_utable *t, float *d_Q, float *d_b, int64_t I, const int32_t *d_users,
+                                    const int32_t *d_pos, const int32_t *d_neg, int64_t B, float lr, float reg, double *d_loss)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_TRY(check_utable(ctx, t));
+    return sgd_step_impl(ctx, t->P, d_Q, d_b, t->U, I, t->d, d_users, d_pos, d_neg, B, lr, reg, d_loss, t);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -949,10 +1090,9 @@ extern "C" int tfrec_batch_prepare_many(tfrec_ctx *ctx, int slot, int64_t U, int
     return TFREC_OK;
 }
 
-extern "C" int tfrec_bpr_sgd_step_prepared(tfrec_ctx *ctx, int slot, float *d_P, float *d_Q, float *d_b, int64_t U, int64_t I,
-                                           int d, float lr, float reg, double *d_loss)
+static int step_prepared_impl(tfrec_ctx *ctx, int slot, float *d_P, float *d_Q, float *d_b, int64_t U, int64_t I, int d, float lr,
+                              float reg, double *d_loss, const tfrec_utable *ut)
 {
-    TF_TRY(tfrec_ctx_enter(ctx));
     TF_REQUIRE(slot == 0 || slot == 1, TFREC_EINVAL, "slot must be 0 or 1");
     tfrec_batch_slot &sl = ctx->slots[slot];
     TF_REQUIRE(sl.B >= 1, TFREC_EINVAL, "slot %d holds no prepared batch", slot);
@@ -961,7 +1101,7 @@ extern "C" int tfrec_bpr_sgd_step_prepared(tfrec_ctx *ctx, int slot, float *d_P,
     TF_HIP(hipStreamWaitEvent(ctx->stream, sl.ready, 0));
     tfrec_marks_reset(ctx);
     tfrec_mark(ctx, "start");
-    const int rc = bpr_passes(ctx, sl, d_P, d_Q, d_b, U, d, lr, reg, d_loss);
+    const int rc = bpr_passes(ctx, sl, d_P, d_Q, d_b, U, d, lr, reg, d_loss, false, nullptr, nullptr, ut);
     if (++sl.next_k >= sl.K) {      // the last batch of the slot: its arrays may be overwritten once this step is done
         TF_HIP(hipEventRecord(sl.released, ctx->stream));
         sl.has_released = true;
@@ -970,15 +1110,29 @@ extern "C" int tfrec_bpr_sgd_step_prepared(tfrec_ctx *ctx, int slot, float *d_P,
     return rc;
 }
 
+extern "C" int tfrec_bpr_sgd_step_prepared(tfrec_ctx *ctx, int slot, float *d_P, float *d_Q, float *d_b, int64_t U, int64_t I,
+                                           int d, float lr, float reg, double *d_loss)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    return step_prepared_impl(ctx, slot, d_P, d_Q, d_b, U, I, d, lr, reg, d_loss, nullptr);
+}
+
+extern "C" int tfrec_bpr_sgd_step_prepared_v(tfrec_ctx *ctx, int slot, tfrec_utable *t, float *d_Q, float *d_b, int64_t I, float lr,
+                                             float reg, double *d_loss)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_TRY(check_utable(ctx, t));
+    return step_prepared_impl(ctx, slot, t->P, d_Q, d_b, t->U, I, t->d, lr, reg, d_loss, t);
+}
+
 // The step for a GPU that holds a shard of P and a full copy of Q, b: P is updated in place; the
 // item side leaves, in the zeroed table G = [I*d gradient rows | I bias gradients], the gradient sum
 // (regularisation term included) of every item this batch touches.  Summing G over the GPUs and
 // applying Q -= lr*G on every copy is the unsharded step.
-extern "C" int tfrec_bpr_dense_grad_step(tfrec_ctx *ctx, int slot, float *d_P, const float *d_Q, const float *d_b, float *d_G,
-                                         int64_t U, int64_t I, int d, const int32_t *d_users, const int32_t *d_pos,
-                                         const int32_t *d_neg, int64_t B, float lr, float reg, double *d_loss)
+static int dense_grad_step_impl(tfrec_ctx *ctx, int slot, float *d_P, const float *d_Q, const float *d_b, float *d_G, int64_t U,
+                                int64_t I, int d, const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg, int64_t B,
+                                float lr, float reg, double *d_loss, const tfrec_utable *ut)
 {
-    TF_TRY(tfrec_ctx_enter(ctx));
     TF_REQUIRE(slot >= -1 && slot <= 1, TFREC_EINVAL, "slot must be -1 (sort now), 0 or 1");
     TF_REQUIRE(d_G != nullptr && ((uintptr_t)d_G & 15u) == 0, TFREC_EINVAL, "gradient table missing or not 16-byte aligned");
     if (slot < 0) TF_TRY(check_step_args(d_P, d_Q, d_b, U, I, d, d_users, d_pos, d_neg, B));
@@ -995,19 +1149,36 @@ extern "C" int tfrec_bpr_dense_grad_step(tfrec_ctx *ctx, int slot, float *d_P, c
         tfrec_batch_slot &sl = ctx->slots[2];
         TF_TRY(slot_prepare(ctx, sl, ctx->stream, d_users, d_pos, d_neg, B, U, I));
         tfrec_mark(ctx, "index");
-        return bpr_passes(ctx, sl, d_P, const_cast<float *>(d_Q), const_cast<float *>(d_b), U, d, lr, reg, d_loss, true, gQ, gb);
+        return bpr_passes(ctx, sl, d_P, const_cast<float *>(d_Q), const_cast<float *>(d_b), U, d, lr, reg, d_loss, true, gQ, gb, ut);
     }
     tfrec_batch_slot &sl = ctx->slots[slot];
     TF_REQUIRE(sl.B >= 1, TFREC_EINVAL, "slot %d holds no prepared batch", slot);
     TF_REQUIRE(sl.U == U && sl.I == I, TFREC_EINVAL, "slot %d was prepared for a %lldx%lld model", slot, (long long)sl.U, (long long)sl.I);
     TF_HIP(hipStreamWaitEvent(ctx->stream, sl.ready, 0));
-    const int rc = bpr_passes(ctx, sl, d_P, const_cast<float *>(d_Q), const_cast<float *>(d_b), U, d, lr, reg, d_loss, true, gQ, gb);
+    const int rc = bpr_passes(ctx, sl, d_P, const_cast<float *>(d_Q), const_cast<float *>(d_b), U, d, lr, reg, d_loss, true, gQ, gb, ut);
     if (++sl.next_k >= sl.K) {
         TF_HIP(hipEventRecord(sl.released, ctx->stream));
         sl.has_released = true;
         sl.B = -1;
     }
     return rc;
+}
+
+extern "C" int tfrec_bpr_dense_grad_step(tfrec_ctx *ctx, int slot, float *d_P, const float *d_Q, const float *d_b, float *d_G,
+                                         int64_t U, int64_t I, int d, const int32_t *d_users, const int32_t *d_pos,
+                                         const int32_t *d_neg, int64_t B, float lr, float reg, double *d_loss)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    return dense_grad_step_impl(ctx, slot, d_P, d_Q, d_b, d_G, U, I, d, d_users, d_pos, d_neg, B, lr, reg, d_loss, nullptr);
+}
+
+extern "C" int tfrec_bpr_dense_grad_step_v(tfrec_ctx *ctx, int slot, tfrec_utable *t, const float *d_Q, const float *d_b, float *d_G,
+                                           int64_t I, const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg, int64_t B,
+                                           float lr, float reg, double *d_loss)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_TRY(check_utable(ctx, t));
+    return dense_grad_step_impl(ctx, slot, t->P, d_Q, d_b, d_G, t->U, I, t->d, d_users, d_pos, d_neg, B, lr, reg, d_loss, t);
 }
 
 __global__ __launch_bounds__(256) void axpy_kernel(float *__restrict__ y, const float *__restrict__ x, float alpha, int64_t n4, int64_t n)

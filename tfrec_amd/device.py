@@ -78,6 +78,36 @@ class DevView:
         return out
 
 
+class UserTable:
+    """A versioned user table (``tfrec_utable``): the caller's ``P`` paired with a second row buffer and one version
+    byte per user inside the library, so that a training step need not stage the pre-step user rows for its item
+    half.  Between ``flatten()`` calls ``P`` is NOT complete: call ``flatten()`` before anything else reads it."""
+
+    def __init__(self, dev, P):
+        self.dev, self.P = dev, P
+        U, d = _shape(P)
+        h = C.c_void_p()
+        _lib.check(dev.lib.tfrec_utable_create(dev.h, _ptr(P), U, d, C.byref(h)))
+        self.h = h.value
+        self.shape = (U, d)
+
+    def flatten(self):
+        """Makes ``P`` complete and current again (stream-ordered); returns ``P``."""
+        _lib.check(self.dev.lib.tfrec_utable_flatten(self.dev.h, self.h))
+        return self.P
+
+    def close(self):
+        if self.h and self.dev.h:
+            _lib.check(self.dev.lib.tfrec_utable_destroy(self.dev.h, self.h))
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def _ptr(x):
     """Device pointer of a DevArray, a torch tensor, an int, or None."""
     if x is None:
@@ -219,6 +249,27 @@ class Device:
         B = _shape(users)[0]
         _lib.check(self.lib.tfrec_bpr_sgd_step(self.h, _ptr(P), _ptr(Q), _ptr(b), U, I, d, _ptr(users), _ptr(pos), _ptr(neg), B,
                                                float(lr), float(reg), _ptr(loss)))
+
+    def user_table(self, P):
+        """Wraps ``P`` in a versioned user table for the ``*_v`` steps (see ``UserTable``)."""
+        return UserTable(self, P)
+
+    def bpr_sgd_step_v(self, ut, Q, b, users, pos, neg, lr, reg, loss=None):
+        """``bpr_sgd_step`` on a versioned user table."""
+        I = _shape(Q)[0]
+        B = _shape(users)[0]
+        _lib.check(self.lib.tfrec_bpr_sgd_step_v(self.h, ut.h, _ptr(Q), _ptr(b), I, _ptr(users), _ptr(pos), _ptr(neg), B,
+                                                 float(lr), float(reg), _ptr(loss)))
+
+    def bpr_sgd_step_prepared_v(self, slot, ut, Q, b, lr, reg, loss=None):
+        I = _shape(Q)[0]
+        _lib.check(self.lib.tfrec_bpr_sgd_step_prepared_v(self.h, int(slot), ut.h, _ptr(Q), _ptr(b), I, float(lr), float(reg), _ptr(loss)))
+
+    def bpr_dense_grad_step_v(self, ut, Q, b, G, users, pos, neg, lr, reg, slot=-1, loss=None):
+        I = _shape(Q)[0]
+        B = _shape(users)[0] if users is not None else 0
+        _lib.check(self.lib.tfrec_bpr_dense_grad_step_v(self.h, int(slot), ut.h, _ptr(Q), _ptr(b), _ptr(G), I, _ptr(users), _ptr(pos),
+                                                        _ptr(neg), B, float(lr), float(reg), _ptr(loss)))
 
     def bpr_sgd_step_noalloc(self, P, Q, b, users, pos, neg, lr, reg, loss=None):
         """``bpr_sgd_step`` for callers that cannot allocate: all device scratch comes from a fixed array inside

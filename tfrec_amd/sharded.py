@@ -112,6 +112,13 @@ class HipBackend:
     def prepare_batch(self, slot, U, I, users, pos, neg):
         self.dev.prepare_batch(slot, U, I, users, pos, neg)
 
+    def user_table(self, P):
+        """A versioned user table over ``P`` (tfrec_utable): steps on it stage no pre-step user rows."""
+        return self.dev.user_table(P)
+
+    def bpr_dense_grad_step_v(self, ut, Q, b, G, users, pos, neg, lr, reg, slot=-1):
+        self.dev.bpr_dense_grad_step_v(ut, Q, b, G, users, pos, neg, lr, reg, slot=slot)
+
     def axpy(self, y, x, alpha):
         self.dev.axpy(y, x, alpha)
 
@@ -218,9 +225,14 @@ class ShardedBprTrainer:
             raise ValueError("item_mode must be 'auto', 'dense' or 'sharded'")
         self.item_mode = item_mode
         nu, ni = self.user_range[1] - self.user_range[0], self.item_range[1] - self.item_range[0]
+        self._ut = None
         # model/base/MatrixFactorization.py:17-21; the stream of random numbers is that of the unsharded
         # table, so the shards of any world size assemble into the same initial model
-        self.P = self._init_rows(self.U, self.user_range, seed * 2 + 1)
+        self._P = self._init_rows(self.U, self.user_range, seed * 2 + 1)
+        # replicated item table + a backend that offers it: the user shard is a versioned table (no staging of
+        # pre-step user rows in the step); reading ``self.P`` flattens it first
+        self._ut = self.backend.user_table(self._P) if item_mode == "dense" and hasattr(self.backend, "user_table") and nu > 0 else None
+        self._ut_dirty = False
         if item_mode == "dense":
             # [Q | b] in one flat buffer, so that one all-reduce and one update cover both
             self._Qb = torch.zeros(self.I * (self.d + 1), dtype=torch.float32, device=device)
@@ -240,6 +252,14 @@ class ShardedBprTrainer:
 
     def _init_rows(self, n_total, rng, seed):
         return self.backend.uniform_rows(rng[0], rng[1], self.d, -0.05, 0.05, seed, self.device)
+
+    @property
+    def P(self):
+        """This rank's user rows, complete and current (a versioned table is flattened first)."""
+        if self._ut is not None and self._ut_dirty:
+            self._ut.flatten()
+            self._ut_dirty = False
+        return self._P
 
     # ------------------------------------------------------------------------------------------
     def _a2a(self, send, send_counts, recv_counts):
@@ -273,7 +293,11 @@ class ShardedBprTrainer:
         if users is not None:
             users = (users.to(torch.int32) - self.user_range[0]).contiguous()
             pos, neg = pos.to(torch.int32).contiguous(), neg.to(torch.int32).contiguous()
-        self.backend.bpr_dense_grad_step(self.P, self.Q_full, self.b_full, self._G, users, pos, neg, self.lr, self.reg, slot=slot)
+        if self._ut is not None:
+            self.backend.bpr_dense_grad_step_v(self._ut, self.Q_full, self.b_full, self._G, users, pos, neg, self.lr, self.reg, slot=slot)
+            self._ut_dirty = True
+        else:
+            self.backend.bpr_dense_grad_step(self._P, self.Q_full, self.b_full, self._G, users, pos, neg, self.lr, self.reg, slot=slot)
         if slot >= 0:
             self._pending.pop(slot, None)        # consumed: the step that read the slot is enqueued
         if prepare_next is not None:
