@@ -102,6 +102,22 @@ size_t tfrec_sort_temp_bytes(size_t n, int end_bit);
 int tfrec_sort_pairs(void *d_temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
                      const uint32_t *vals_in, uint32_t *vals_out, size_t n, int end_bit, hipStream_t stream);
 
+// The 3n (key, occurrence) pairs of n index triples, never materialised: the first pass of the sort reads them
+// straight from the caller's arrays (range check and clamping included) and leaves the checked (i, j) of every
+// triple in `pair`.  Pair e < n is the user side of triple e; pair n + 2t + side is item side `side` of triple t.
+// K consecutive batches of B triples: the batch number t / B goes above bit `kb` of every key, occurrence ids are
+// local to the batch (user side: tau, item sides: 2 tau and 2 tau + 1).
+struct tfrec_triple_src {
+    const int32_t *users, *pos, *neg;
+    uint32_t n, B, U, I;
+    uint32_t inv_B;       // ceil(2^32 / B) (0 when n <= B: one batch, no batch numbers)
+    int kb;
+    uint32_t *pair;       // [2n] = uint2[n]: (i, j) range-checked
+    uint32_t *flags;      // sticky error flags
+};
+int tfrec_sort_triples(void *d_temp, size_t temp_bytes, const tfrec_triple_src &src, uint32_t *keys_out, uint32_t *vals_out,
+                       int end_bit, hipStream_t stream);
+
 // ------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------

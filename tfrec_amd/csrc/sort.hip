@@ -46,8 +46,44 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wave_s
     return before + inc - v;
 }
 
-template <int RB, int ITEMS>
-__global__ __launch_bounds__(256) void sort_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n, int shift, uint32_t dmask,
+// Where a pass reads its pairs from: two arrays, or (first pass of a training batch) the index triples themselves.
+// The loads are straight-line code (selects, no branches), so that a lane's ITEMS loads are all in flight together.
+struct PlainSrc {
+    const uint32_t *__restrict__ k, *__restrict__ v;
+    __device__ __forceinline__ uint32_t key(uint32_t i) const { return k[i]; }
+    __device__ __forceinline__ void load(uint32_t i, uint32_t &key_, uint32_t &val_, bool &) const { key_ = k[i]; val_ = v[i]; }
+    __device__ __forceinline__ void report(bool) const {}
+};
+
+struct TripleSrc {
+    tfrec_triple_src a;
+    // WRITE: the scatter pass (which sees every pair exactly once) leaves the checked items in `pair`
+    template <bool WRITE>
+    __device__ __forceinline__ void get(uint32_t i, uint32_t &key_, uint32_t &val_, bool &bad) const
+    {
+        const bool is_user = i < a.n;
+        const uint32_t e = i - a.n, side = is_user ? 0u : (e & 1u);
+        const uint32_t t = is_user ? i : (e >> 1);
+        const int32_t *src = is_user ? a.users : (side ? a.neg : a.pos);
+        const int32_t x = src[t];
+        const uint32_t lim = is_user ? a.U : a.I;
+        bad = bad || x < 0 || (uint32_t)x >= lim;
+        const uint32_t c = x < 0 ? 0u : ((uint32_t)x >= lim ? lim - 1 : (uint32_t)x);
+        // batch number t / B without a division: multiply by the rounded-up reciprocal, step back if that overshot
+        uint32_t k = a.inv_B ? __umulhi(t, a.inv_B) : 0u;
+        k -= (k * a.B > t) ? 1u : 0u;
+        const uint32_t tau = t - k * a.B;
+        key_ = (k << a.kb) | (is_user ? c : a.U + c);
+        val_ = is_user ? tau : 2 * tau + side;
+        if constexpr (WRITE) if (!is_user) a.pair[e] = c;
+    }
+    __device__ __forceinline__ uint32_t key(uint32_t i) const { uint32_t k, v; bool bad = false; get<false>(i, k, v, bad); return k; }
+    __device__ __forceinline__ void load(uint32_t i, uint32_t &key_, uint32_t &val_, bool &bad) const { get<true>(i, key_, val_, bad); }
+    __device__ __forceinline__ void report(bool bad) const { if (bad) atomicOr(a.flags, TFREC_FLAG_BAD_INDEX); }
+};
+
+template <int RB, int ITEMS, class Src>
+__global__ __launch_bounds__(256) void sort_hist_kernel(Src src, uint32_t n, int shift, uint32_t dmask,
                                                         uint32_t *__restrict__ counts, uint32_t nblk)
 {
     constexpr int BINS = 1 << RB, TILE = 256 * ITEMS;
@@ -59,7 +95,8 @@ __global__ __launch_bounds__(256) void sort_hist_kernel(const uint32_t *__restri
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         const uint32_t i = base + r * 256 + threadIdx.x;
-        if (i < n) atomicAdd(&h[w][(keys[i] >> shift) & dmask], 1u);
+        const uint32_t kk = src.key(i < n ? i : n - 1);
+        if (i < n) atomicAdd(&h[w][(kk >> shift) & dmask], 1u);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < BINS; b += 256) {
@@ -89,8 +126,8 @@ __global__ __launch_bounds__(256) void sort_scan_kernel(uint32_t *__restrict__ c
     if (threadIdx.x == 0) digit_total[blockIdx.x] = total;
 }
 
-template <int RB, int ITEMS>
-__global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+template <int RB, int ITEMS, class Src>
+__global__ __launch_bounds__(256) void sort_scatter_kernel(Src src,
                                                            uint32_t *__restrict__ kout, uint32_t *__restrict__ vout, uint32_t n, int shift,
                                                            uint32_t dmask, const uint32_t *__restrict__ prefix,
                                                            const uint32_t *__restrict__ digit_total, uint32_t nblk)
@@ -109,12 +146,13 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t *__res
     const uint32_t tile0 = blockIdx.x * (uint32_t)TILE;
     const uint32_t wbase = tile0 + w * PER_WAVE;
     uint32_t k[ITEMS], v[ITEMS], rank[ITEMS];
+    bool bad = false;
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         const uint32_t i = wbase + r * 64 + lane;
-        k[r] = i < n ? kin[i] : 0u;
-        v[r] = i < n ? vin[i] : 0u;
+        src.load(i < n ? i : n - 1, k[r], v[r], bad);      // (a lane past the end repeats the last pair; it is never ranked)
     }
+    src.report(bad);
     // Wave w holds PER_WAVE consecutive pairs, 64 consecutive ones per round.  Lanes with the same
     // digit find each other with one ballot per digit bit; their order among themselves is lane
     // order, and the lowest of them advances the wave's counter of that digit.
@@ -226,35 +264,41 @@ SortPlan sort_plan(size_t n, int end_bit)
     return p;
 }
 
-template <int RB, int ITEMS>
-int sort_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, uint32_t n, int shift, uint32_t dmask,
+template <int RB, int ITEMS, class Src>
+int sort_pass(const Src &src, uint32_t *kout, uint32_t *vout, uint32_t n, int shift, uint32_t dmask,
               uint32_t *counts, uint32_t *totals, uint32_t nblk, hipStream_t stream)
 {
-    sort_hist_kernel<RB, ITEMS><<<nblk, 256, 0, stream>>>(kin, n, shift, dmask, counts, nblk);
+    sort_hist_kernel<RB, ITEMS, Src><<<nblk, 256, 0, stream>>>(src, n, shift, dmask, counts, nblk);
     sort_scan_kernel<<<1 << RB, 256, 0, stream>>>(counts, nblk, totals);
-    sort_scatter_kernel<RB, ITEMS><<<nblk, 256, 0, stream>>>(kin, vin, kout, vout, n, shift, dmask, counts, totals, nblk);
+    sort_scatter_kernel<RB, ITEMS, Src><<<nblk, 256, 0, stream>>>(src, kout, vout, n, shift, dmask, counts, totals, nblk);
     TF_HIP(hipGetLastError());
     return TFREC_OK;
 }
 
-template <int RB>
-int sort_pass_items(int items, const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, uint32_t n, int shift,
+template <int RB, class Src>
+int sort_pass_items(int items, const Src &src, uint32_t *kout, uint32_t *vout, uint32_t n, int shift,
                     uint32_t dmask, uint32_t *counts, uint32_t *totals, uint32_t nblk, hipStream_t stream)
 {
-    if (items == 16) return sort_pass<RB, 16>(kin, vin, kout, vout, n, shift, dmask, counts, totals, nblk, stream);
-    return sort_pass<RB, 8>(kin, vin, kout, vout, n, shift, dmask, counts, totals, nblk, stream);
+    if (items == 16) return sort_pass<RB, 16, Src>(src, kout, vout, n, shift, dmask, counts, totals, nblk, stream);
+    return sort_pass<RB, 8, Src>(src, kout, vout, n, shift, dmask, counts, totals, nblk, stream);
 }
 
-}  // namespace
-
-size_t tfrec_sort_temp_bytes(size_t n, int end_bit)
+template <class Src>
+int sort_pass_rb(int rb, int items, const Src &src, uint32_t *kout, uint32_t *vout, uint32_t n, int shift, uint32_t dmask,
+                 uint32_t *counts, uint32_t *totals, uint32_t nblk, hipStream_t stream)
 {
-    const SortPlan p = sort_plan(n, end_bit);
-    return p.counts_bytes + p.total_bytes + 2 * p.tmp_bytes + 256;
+    switch (rb) {
+        case 6: return sort_pass_items<6, Src>(items, src, kout, vout, n, shift, dmask, counts, totals, nblk, stream);
+        case 7: return sort_pass_items<7, Src>(items, src, kout, vout, n, shift, dmask, counts, totals, nblk, stream);
+        case 8: return sort_pass_items<8, Src>(items, src, kout, vout, n, shift, dmask, counts, totals, nblk, stream);
+    }
+    tfrec_set_error("internal: no sort kernel for %d-bit digits", rb);
+    return TFREC_EUNSUP;
 }
 
-int tfrec_sort_pairs(void *d_temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
-                     const uint32_t *vals_in, uint32_t *vals_out, size_t n, int end_bit, hipStream_t stream)
+// first_src: where the first pass reads its pairs (null: keys_in / vals_in)
+int sort_run(void *d_temp, size_t temp_bytes, const TripleSrc *first_src, const uint32_t *keys_in, const uint32_t *vals_in,
+             uint32_t *keys_out, uint32_t *vals_out, size_t n, int end_bit, hipStream_t stream)
 {
     if (n == 0) return TFREC_OK;
     TF_REQUIRE(n < (1ull << 32), TFREC_EUNSUP, "sort of %zu pairs: positions must fit 32 bits", n);
@@ -274,20 +318,34 @@ int tfrec_sort_pairs(void *d_temp, size_t temp_bytes, const uint32_t *keys_in, u
         const int shift = pass * p.rb;
         const int bits = end_bit - shift < p.rb ? end_bit - shift : p.rb;
         const uint32_t dmask = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
-        int rc = TFREC_EUNSUP;
-        switch (p.rb) {
-            case 6: rc = sort_pass_items<6>(p.items, kin, vin, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream); break;
-            case 7: rc = sort_pass_items<7>(p.items, kin, vin, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream); break;
-            case 8: rc = sort_pass_items<8>(p.items, kin, vin, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream); break;
-            case 9: rc = sort_pass_items<9>(p.items, kin, vin, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream); break;
-            case 10: rc = sort_pass_items<10>(p.items, kin, vin, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream); break;
-            case 11: rc = sort_pass_items<11>(p.items, kin, vin, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream); break;
-            default: tfrec_set_error("internal: no sort kernel for %d-bit digits", p.rb);
-        }
+        int rc;
+        if (pass == 0 && first_src) rc = sort_pass_rb<TripleSrc>(p.rb, p.items, *first_src, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream);
+        else rc = sort_pass_rb<PlainSrc>(p.rb, p.items, PlainSrc{kin, vin}, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream);
         if (rc != TFREC_OK) return rc;
         kin = ko; vin = vo;
     }
     return TFREC_OK;
+}
+
+}  // namespace
+
+size_t tfrec_sort_temp_bytes(size_t n, int end_bit)
+{
+    const SortPlan p = sort_plan(n, end_bit);
+    return p.counts_bytes + p.total_bytes + 2 * p.tmp_bytes + 256;
+}
+
+int tfrec_sort_pairs(void *d_temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
+                     const uint32_t *vals_in, uint32_t *vals_out, size_t n, int end_bit, hipStream_t stream)
+{
+    return sort_run(d_temp, temp_bytes, nullptr, keys_in, vals_in, keys_out, vals_out, n, end_bit, stream);
+}
+
+int tfrec_sort_triples(void *d_temp, size_t temp_bytes, const tfrec_triple_src &src, uint32_t *keys_out, uint32_t *vals_out,
+                       int end_bit, hipStream_t stream)
+{
+    const TripleSrc ts{src};
+    return sort_run(d_temp, temp_bytes, &ts, nullptr, nullptr, keys_out, vals_out, (size_t)3 * src.n, end_bit, stream);
 }
 
 extern "C" int tfrec_sort_pairs_u32(tfrec_ctx *ctx, const uint32_t *d_keys_in, const uint32_t *d_vals_in, uint32_t *d_keys_out,

@@ -5,15 +5,18 @@
 // One step, for a batch of B triples (u, i, j):
 //   1. index (can run ahead on a second stream, see tfrec_batch_prepare)
 //        3B (key, occurrence) pairs: key u for the user side, U+item for both item sides,
-//        range-checked (clamped + sticky flag), then ONE stable radix sort by key: user
-//        occurrences land in [0,B), item occurrences in [B,3B)
+//        range-checked (clamped + sticky flag), in ONE stable radix sort by key whose first pass
+//        reads the index triples themselves: user occurrences land in [0,B), item occurrences
+//        in [B,3B)
 //   2. user pass   gather P[u], Q[i], Q[j] -> s = sigma(-x); sum the user gradient per distinct
-//                  u and update P[u] in place; leave s and the pre-step P[u] of every triple in
-//                  a staging area
-//   3. item pass   per item occurrence: gather the staged s and P[u] -> sum the item gradient
+//                  u and update P[u]; leave s of every triple for the item pass
+//   3. item pass   per item occurrence: gather s and the PRE-step P[u] -> sum the item gradient
 //                  per distinct item and update Q, b in place
-// Step 3 reads only the staging area, never P, so every gradient is taken at the pre-step
-// parameters although both tables are updated in place.
+// Every gradient is taken at the pre-step parameters although both tables are updated.  Plain user
+// table: step 2 updates P in place and stages a copy of the pre-step P[u] of every triple, which
+// is all that step 3 reads.  Versioned user table (tfrec_utable): step 2 writes the updated row
+// into the row's other buffer, step 3 reads the pre-step row where it still is, and the version
+// bytes of the batch's users are flipped at the end: no copies.
 #include "seg_pass.hpp"
 
 #include <atomic>
@@ -26,26 +29,6 @@ __device__ __forceinline__ uint32_t clamp_index(int32_t v, uint32_t n, bool *bad
     if (v < 0) { *bad = true; return 0u; }
     if ((uint32_t)v >= n) { *bad = true; return n - 1; }
     return (uint32_t)v;
-}
-
-// n = K*B triples of K consecutive batches; batch number k = t / B goes above bit `kb` of every key, so
-// one sort groups by (batch, side, row); occurrence ids are local to the batch
-__global__ __launch_bounds__(256) void build_keys_kernel(const int32_t *__restrict__ users, const int32_t *__restrict__ pos,
-                                                         const int32_t *__restrict__ neg, int64_t n, int64_t B, int kb, uint32_t U,
-                                                         uint32_t I, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                         uint2 *__restrict__ pair, uint32_t *__restrict__ flags)
-{
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n) return;
-    bool bad = false;
-    const uint32_t u = clamp_index(users[t], U, &bad), i = clamp_index(pos[t], I, &bad), j = clamp_index(neg[t], I, &bad);
-    if (bad) atomicOr(flags, TFREC_FLAG_BAD_INDEX);
-    const uint32_t k = (uint32_t)(t / B), tau = (uint32_t)(t - (int64_t)k * B), hi = k << kb;
-    keys[t] = hi | u;
-    vals[t] = tau;
-    reinterpret_cast<uint2 *>(keys + n)[t] = make_uint2(hi | (U + i), hi | (U + j));
-    reinterpret_cast<uint2 *>(vals + n)[t] = make_uint2(2 * tau, 2 * tau + 1);
-    pair[t] = make_uint2(i, j);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -633,7 +616,7 @@ static int bits_for(uint64_t n)   // bits needed to represent values < n
 static size_t slot_bytes(int64_t n, size_t *sort_bytes)
 {
     *sort_bytes = tfrec_sort_temp_bytes((size_t)3 * n, 32);
-    return 4 * tf_align(12 * (size_t)n) + tf_align(8 * (size_t)n) + tf_align(*sort_bytes) + 4096;
+    return 2 * tf_align(12 * (size_t)n) + tf_align(8 * (size_t)n) + tf_align(*sort_bytes) + 4096;
 }
 
 // Sorts K consecutive batches of B triples (K*B index triples) into slot `sl`.
@@ -658,15 +641,15 @@ static int slot_prepare(tfrec_ctx *ctx, tfrec_batch_slot &sl, hipStream_t stream
     }
     char *p = sl.mem;
     auto take = [&](size_t bytes) { char *r = p; p += tf_align(bytes); return r; };
-    uint32_t *keys_in = (uint32_t *)take(12 * (size_t)n), *vals_in = (uint32_t *)take(12 * (size_t)n);
     sl.keys = (uint32_t *)take(12 * (size_t)n);
     sl.vals = (uint32_t *)take(12 * (size_t)n);
     sl.pair = (uint2 *)take(8 * (size_t)n);
     void *sort_tmp = take(sort_bytes);
-    build_keys_kernel<<<(int)((n + 255) / 256), 256, 0, stream>>>(users, pos, neg, n, B, kb, (uint32_t)U, (uint32_t)I, keys_in,
-                                                                 vals_in, sl.pair, ctx->d_flags);
-    TF_HIP(hipGetLastError());
-    TF_TRY(tfrec_sort_pairs(sort_tmp, sort_bytes, keys_in, sl.keys, vals_in, sl.vals, (size_t)3 * n, total_bits, stream));
+    // the first sort pass reads the index triples themselves (range check included) and leaves the checked items in pair
+    const uint32_t inv_B = K > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)B - 1) / (uint64_t)B) : 0u;
+    const tfrec_triple_src src{users, pos, neg, (uint32_t)n, (uint32_t)B, (uint32_t)U, (uint32_t)I, inv_B, kb,
+                               reinterpret_cast<uint32_t *>(sl.pair), ctx->d_flags};
+    TF_TRY(tfrec_sort_triples(sort_tmp, sort_bytes, src, sl.keys, sl.vals, total_bits, stream));
     sl.B = B; sl.U = U; sl.I = I; sl.K = K; sl.next_k = 0; sl.apr_pending = 0;
     sl.users_raw = users; sl.pos_raw = pos; sl.neg_raw = neg;
     sl.kmask = kb >= 32 ? 0xffffffffu : ((1u << kb) - 1u);
