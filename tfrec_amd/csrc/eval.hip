@@ -231,8 +231,12 @@ extern "C" int tfrec_debug_prof(unsigned long long *out, int reset)
 // bits (one wave-uniform count per bit: compares, ballots and scalar population counts; the low
 // half -- the id -- only when scores tie at the cut), which costs an order of magnitude fewer
 // vector instructions than the sort.  The survivors are written back in lane order.
-template <int CAP, class Out>
-__device__ __forceinline__ int wave_select(const uint64_t *list, int cnt, int ver, int k,
+// A candidate list is two regions of CAP/2 entries, one per lane that holds items of the user (each lane appends to
+// its own region without asking the other): region r holds cnt_r entries, the first ver_r of them known not to be
+// masked.  INTERLEAVE: survivor j is written to region j & 1, slot j >> 1 (the list itself: both regions get half);
+// else to out[j] (the sort buffer of the final pass).
+template <int CAP, bool INTERLEAVE, class Out>
+__device__ __forceinline__ int wave_select(const uint64_t *list, int cnt0, int cnt1, int ver0, int ver1, int k,
                                            const int32_t *__restrict__ mask_idx, int64_t mlo, int64_t mhi,
                                            volatile uint64_t *sortbuf, int lane, float *tau_out, Out out,
                                            [[maybe_unused]] unsigned long long *prof_acc = nullptr)
@@ -245,14 +249,15 @@ __device__ __forceinline__ int wave_select(const uint64_t *list, int cnt, int ve
     if (prof_acc) { prof_acc[8] += TF_PROF_T() - prof_t; prof_t = TF_PROF_T(); }
 #endif
     const int64_t L = mhi - mlo;
-    const bool check = mask_idx != nullptr && L > 0 && ver < cnt;
+    const bool check = mask_idx != nullptr && L > 0 && (ver0 < cnt0 || ver1 < cnt1);
     const bool staged = check && L <= ROWCAP;
     volatile int32_t *rowbuf = reinterpret_cast<volatile int32_t *>(sortbuf);
+    constexpr int HQ = EPL / 2;               // register slots per region
     uint64_t keys[EPL];
 #pragma unroll
     for (int q = 0; q < EPL; ++q) {
-        const int e = lane + 64 * q;
-        keys[q] = e < cnt ? list[e] : 0;
+        const int e = lane + 64 * (q % HQ);
+        keys[q] = e < (q < HQ ? cnt0 : cnt1) ? list[(q / HQ) * (CAP / 2) + e] : 0;
     }
     // short rows are padded to whole groups of four with an id no key carries
     constexpr int LINEAR_MAX = 64;
@@ -287,8 +292,8 @@ __device__ __forceinline__ int wave_select(const uint64_t *list, int cnt, int ve
     } else if (check) {
 #pragma unroll
         for (int q = 0; q < EPL; ++q) {
-            const int e = lane + 64 * q;
-            if (e < cnt && e >= ver) {
+            const int e = lane + 64 * (q % HQ);
+            if (e < (q < HQ ? cnt0 : cnt1) && e >= (q < HQ ? ver0 : ver1)) {
                 const int32_t id = key_id(keys[q]);
                 bool hit;
                 if (staged) {
@@ -397,7 +402,8 @@ __device__ __forceinline__ int wave_select(const uint64_t *list, int cnt, int ve
     for (int q = 0; q < EPL; ++q) {
         const bool keep = keys[q] >= cut;
         const uint64_t m = __ballot(keep);
-        if (keep) out[base + __popcll(m & ((1ull << lane) - 1ull))] = keys[q];
+        const int j = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (keep) out[INTERLEAVE ? (j & 1) * (CAP / 2) + (j >> 1) : j] = keys[q];
         base += __popcll(m);
     }
     *tau_out = kept >= k ? key_score(cut) : -INFINITY;
@@ -411,7 +417,7 @@ __device__ __forceinline__ int wave_select(const uint64_t *list, int cnt, int ve
 // End of the scan: select the k survivors into the wave's LDS buffer (the staged row is no longer
 // needed once the selection has its keys in registers), sort just those, leave them in sortbuf[0..n).
 template <int CAP>
-__device__ __forceinline__ int wave_finish(const uint64_t *__restrict__ list, int cnt, int ver, int k,
+__device__ __forceinline__ int wave_finish(const uint64_t *__restrict__ list, int cnt0, int cnt1, int ver0, int ver1, int k,
                                            const int32_t *__restrict__ mask_idx, int64_t mlo, int64_t mhi,
                                            volatile uint64_t *sortbuf, int lane)
 {
@@ -419,8 +425,8 @@ __device__ __forceinline__ int wave_finish(const uint64_t *__restrict__ list, in
     float tau;
     // a list that fits the sort as it is needs no selection first (asking for more survivors than it can
     // hold makes the selection keep every unmasked entry); the sort then puts the best k in front
-    const bool small = cnt <= SN;
-    const int held = wave_select<CAP>(list, cnt, ver, small ? CAP : k, mask_idx, mlo, mhi, sortbuf, lane, &tau, sortbuf);
+    const bool small = cnt0 + cnt1 <= SN;
+    const int held = wave_select<CAP, false>(list, cnt0, cnt1, ver0, ver1, small ? CAP : k, mask_idx, mlo, mhi, sortbuf, lane, &tau, sortbuf);
     const int nc = held < k ? held : k;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -498,12 +504,18 @@ struct ScoreWave<256, true, CAP> { static constexpr int UW = 1, NW = 8; };
 template <int CAP>
 struct ScoreWave<64, false, CAP> { static constexpr int UW = 1, NW = 8; };
 
+// LDS bytes of an instantiation with tiles of `ti` items
+constexpr int score_lds_bytes(int ti, int rowb, int nw, int cap) { return 2 * ti * rowb + 2 * ti * 4 + nw * cap * 8 + 1536; }
+
 template <int D, bool BF16, int CAP>
 struct ScoreGeom {
     static constexpr int ESZ = BF16 ? 2 : 4;
-    // items per step; a workgroup of sixteen waves is alone on its CU and takes tiles twice as long (half the barriers)
-    static constexpr int TI = (D * ESZ >= 256 ? 64 : 128) * (ScoreWave<D, BF16, CAP>::NW == 16 ? 2 : 1);
     static constexpr int ROWB = D * ESZ + 16;                // padded LDS row (bank spread)
+    // items per step; a workgroup of sixteen waves is alone on its CU and takes tiles three times as long (a third of
+    // the barriers) where the CU's 160 KB hold two of them beside the sort buffers, else twice as long
+    static constexpr int TI0 = D * ESZ >= 256 ? 64 : 128;
+    static constexpr int TI = ScoreWave<D, BF16, CAP>::NW != 16 ? TI0
+                              : (score_lds_bytes(3 * TI0, ROWB, 16, CAP) <= 160 * 1024 ? 3 * TI0 : 2 * TI0);
     static constexpr int CPR = D * ESZ / 16;                 // 16-byte chunks per row
     static constexpr int NW = ScoreWave<D, BF16, CAP>::NW, NT = 64 * NW;   // waves / threads per workgroup
     static constexpr int NLD = TI * CPR / NT;                // chunks per thread per tile
@@ -538,9 +550,10 @@ __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk
     const int64_t it0 = (int64_t)blockIdx.y * a.split_items;             // first item (shard-relative)
     const int64_t it1 = it0 + a.split_items < a.n_items ? it0 + a.split_items : a.n_items;
 
-    // Per user set: candidate-list state of the lane's user, kept in registers by BOTH lanes that
-    // hold items of that user (lane and lane^32): entries held, entries already checked against the
-    // train row, and the threshold (the user's k-th best score so far; +inf keeps padding users out).
+    // Per user set: candidate-list state of the lane's user.  The two lanes that hold items of one user (lane and
+    // lane^32) each append to their own half of the user's list and keep its count and the count of its entries
+    // already checked against the train row; both keep the threshold (the user's k-th best score so far; +inf
+    // keeps padding users out).
     uint64_t *mylist[UW];
     int64_t mlo[UW], mhi[UW];
     int mycnt[UW], myver[UW];
@@ -553,7 +566,7 @@ __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk
         const bool uvalid = ur < a.n;
         const int64_t urc = uvalid ? ur : a.n - 1;
         const int32_t user = a.users[urc];
-        mylist[s] = a.lists + ((size_t)blockIdx.y * a.n + urc) * CAP;
+        mylist[s] = a.lists + ((size_t)blockIdx.y * a.n + urc) * CAP + h * (CAP / 2);      // this lane's region of the user's list
         mlo[s] = a.train_indptr ? a.train_indptr[user] : 0;
         mhi[s] = a.train_indptr ? a.train_indptr[user + 1] : 0;
         mycnt[s] = 0; myver[s] = 0;
@@ -687,12 +700,9 @@ __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk
                         if (__ballot(gm[g] > th[s]) != 0) {
 #pragma unroll
                             for (int r = 4 * g; r < 4 * g + 4; ++r) {
-                                const bool pass = acc[s][r] > th[s];
-                                if (__ballot(pass) != 0) {
-                                    // the user's two lanes append in lane order; both keep the same count
-                                    const uint32_t other = swap32(pass ? 1u : 0u, lane);
-                                    if (pass) mylist[s][mycnt[s] + (h ? (int)other : 0)] = make_key(acc[s][r], id0 + (r & 3) + 8 * (r >> 2));
-                                    mycnt[s] += (pass ? 1 : 0) + (int)other;
+                                if (acc[s][r] > th[s]) {        // per lane: an append asks nobody
+                                    mylist[s][mycnt[s]] = make_key(acc[s][r], id0 + (r & 3) + 8 * (r >> 2));
+                                    mycnt[s] += 1;
                                 }
                             }
                         }
@@ -702,7 +712,9 @@ __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk
                 }
                 TF_PROF_ADD(1, prof_t_ins);
                 // a list that could overflow during the next 32 items is compacted now
-                uint64_t need = __ballot(lane < 32 && mycnt[s] > CAP - 32);
+                // (a lane adds at most its 16 items of a block of 32 to its half)
+                uint64_t need = __ballot(mycnt[s] > CAP / 2 - 16);
+                need = (need | (need >> 32)) & 0xffffffffull;          // by user
                 [[maybe_unused]] const unsigned long long prof_t_cmp = TF_PROF_T();
                 while (need) {
                     prof_acc[5] += 1;
@@ -719,10 +731,12 @@ __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk
                     // mid-scan compaction; the threshold is a few ranks looser.)
                     const int64_t L = shi - slo;
                     const bool defer = a.train_indices != nullptr && a.k + L <= CAP / 2;
-                    const int nc = wave_select<CAP>(sl, __builtin_amdgcn_readlane(mycnt[s], src), __builtin_amdgcn_readlane(myver[s], src),
-                                                    defer ? a.k + (int)L : a.k, defer ? nullptr : a.train_indices, slo, shi, mysort, lane,
-                                                    &nt, sl, prof_acc);
-                    if (uj == src) { mycnt[s] = nc; myver[s] = defer ? 0 : nc; th[s] = nt; }
+                    const int nc = wave_select<CAP, true>(sl, __builtin_amdgcn_readlane(mycnt[s], src), __builtin_amdgcn_readlane(mycnt[s], src + 32),
+                                                          __builtin_amdgcn_readlane(myver[s], src), __builtin_amdgcn_readlane(myver[s], src + 32),
+                                                          defer ? a.k + (int)L : a.k, defer ? nullptr : a.train_indices, slo, shi, mysort, lane,
+                                                          &nt, sl, prof_acc);
+                    // the survivors went alternately to the two halves
+                    if (uj == src) { mycnt[s] = (nc + 1 - h) >> 1; myver[s] = defer ? 0 : mycnt[s]; th[s] = nt; }
                 }
                 TF_PROF_ADD(2, prof_t_cmp);
             }
@@ -745,7 +759,8 @@ __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk
             if (sur >= a.n) break;     // wave-uniform
             uint64_t *sl = a.lists + ((size_t)blockIdx.y * a.n + sur) * CAP;
             const int64_t slo = __shfl(mlo[s], src, 64), shi = __shfl(mhi[s], src, 64);
-            const int nc = wave_finish<CAP>(sl, __builtin_amdgcn_readlane(mycnt[s], src), __builtin_amdgcn_readlane(myver[s], src), a.k,
+            const int nc = wave_finish<CAP>(sl, __builtin_amdgcn_readlane(mycnt[s], src), __builtin_amdgcn_readlane(mycnt[s], src + 32),
+                                            __builtin_amdgcn_readlane(myver[s], src), __builtin_amdgcn_readlane(myver[s], src + 32), a.k,
                                             a.train_indices, slo, shi, mysort, lane);
             int32_t *oi = a.out_ids + ((size_t)blockIdx.y * a.n + sur) * a.k;
             float *os = a.out_scores + ((size_t)blockIdx.y * a.n + sur) * a.k;
@@ -1110,7 +1125,7 @@ static int plan_score(const float *d_Q, int d, int64_t item_lo, int64_t item_hi,
     p->n_items = item_hi - item_lo;
     p->bf16 = score_mode == TFREC_SCORE_BF16;
     p->direct = !p->bf16 && d == p->D && (((uintptr_t)d_Q) & 15u) == 0;
-    p->TI = 256;      // a multiple of every ScoreGeom::TI
+    p->TI = 768;      // a multiple of every ScoreGeom::TI
     p->chunk = 1 << 20;          // users per launch: bounds the candidate-list workspace
     // waves per workgroup of the instantiation that will run (ScoreWave<D, BF16, CAP>::NW)
     const int nw = p->bf16 ? (p->D == 64 ? 16 : (p->D == 128 ? (p->CAP <= 256 ? 16 : 8) : (p->D == 256 ? 8 : 4))) : (p->D == 64 ? 8 : 4);

@@ -38,9 +38,15 @@ struct Acc {
     __device__ __forceinline__ void add(const Acc &o) { v = v + o.v; s0 += o.s0; s1 += o.s1; cnt += o.cnt; }
 };
 
+// occurrences per tile (at least one per lane of the group)
+#ifndef TF_TILE_CH
+#define TF_TILE_CH 64
+#endif
+constexpr int tile_ch(int lpr) { return lpr > TF_TILE_CH ? lpr : TF_TILE_CH; }
+
 template <int LPR>
 struct TileGeom {
-    static constexpr int CH = LPR > 32 ? LPR : 32;   // occurrences per tile
+    static constexpr int CH = tile_ch(LPR);          // occurrences per tile
     static constexpr int EPL = CH / LPR;             // entries staged per lane
     static constexpr int GPB = 256 / LPR;            // groups (= tiles) per 256-thread workgroup
 };

@@ -668,7 +668,7 @@ struct StepWs {
 
 static size_t step_ws_bytes(int64_t B, int d, const RowCfg &c)
 {
-    const int CH = c.lpr > 32 ? c.lpr : 32;
+    const int CH = tile_ch(c.lpr);
     const int64_t tiles = (2 * B + CH - 1) / CH + 1;      // the larger (item) side
     const size_t rowf = (size_t)c.lpr * c.nch * c.vec;
     size_t s = 0;
@@ -701,7 +701,7 @@ size_t tfrec_step_need_bytes(int64_t B, int d)
 static int step_ws_carve(tfrec_ctx *ctx, int64_t B, int d, const RowCfg &c, StepWs *w, bool with_stage = true)
 {
     TF_TRY(tfrec_ws_require(ctx, ctx->ws_used + step_ws_bytes(B, d, c)));
-    const int CH = c.lpr > 32 ? c.lpr : 32, GPB = 256 / c.lpr;
+    const int CH = tile_ch(c.lpr), GPB = 256 / c.lpr;
     const int64_t tiles = (2 * B + CH - 1) / CH + 1;
     const size_t rowf = (size_t)c.lpr * c.nch * c.vec;
     w->stage = with_stage ? (float *)tfrec_ws_take(ctx, sizeof(float) * (size_t)B * d) : nullptr;
@@ -908,7 +908,7 @@ extern "C" int tfrec_rows_sgd_apply(tfrec_ctx *ctx, float *d_Q, float *d_b, int6
     TF_REQUIRE(d_ids && d_grad_rows && d_grad_b, TFREC_EINVAL, "null pointer");
     RowCfg cfg;
     TF_REQUIRE(pick_cfg(d, all_aligned16({d_Q, d_grad_rows}), &cfg), TFREC_EUNSUP, "factor size d=%d is not supported (max 256)", d);
-    const int CH = cfg.lpr > 32 ? cfg.lpr : 32, GPB = 256 / cfg.lpr;
+    const int CH = tile_ch(cfg.lpr), GPB = 256 / cfg.lpr;
     const int64_t tiles = (n + CH - 1) / CH + 1;
     const size_t rowf = (size_t)cfg.lpr * cfg.nch * cfg.vec;
     const int end_bit = bits_for((uint64_t)I);
