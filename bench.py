@@ -290,7 +290,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend for N>1 (gloo: testing only)")
     ap.add_argument("--single-device", action="store_true", help="testing: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--plain-table", action="store_true", help="single GPU: plain user table (pre-step rows staged per triple) instead of the versioned one")
-    ap.add_argument("--extras", action="store_true", help="also time the reference batch size (512 triples per step)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the timing of the reference batch size (512 triples per step)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -536,21 +536,23 @@ def main():
                 "phases_ms": acc, "dominant_phase": dom,
                 "dominant_phase_algorithmic_GBs": B * (16 * d + 20) / (acc[dom] * 1e-3) / 1e9 if dom == "user_tile" else None,
             }
-            if args.extras:
-                # the reference batch size (conf/BPR.ini: 512 triples per step): launch-bound
+            if not args.no_extras:
+                # the reference batch size (conf/BPR.ini:4: 512 triples per step): five short kernels, latency-bound
                 e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 small = 512
-                for s in range(20):
-                    o = s * small
-                    dev.bpr_sgd_step(P, Q, b, users[o:o + small], pos[o:o + small], neg[o:o + small], lr, reg)
-                e2.record(stream)
-                for s in range(200):
-                    o = (s % 1000) * small
-                    dev.bpr_sgd_step(P, Q, b, users[o:o + small], pos[o:o + small], neg[o:o + small], lr, reg)
-                e3.record(stream)
-                torch.cuda.synchronize()
-                out["reference_batch_512"] = {"triples_per_s": 200 * small / (e2.elapsed_time(e3) * 1e-3),
-                                              "us_per_step": e2.elapsed_time(e3) * 1e3 / 200}
+                ref = {}
+                for name, fn in (("bpr_sgd_step", dev.bpr_sgd_step), ("bpr_sgd_step_noalloc", dev.bpr_sgd_step_noalloc)):
+                    for s in range(20):
+                        o = s * small
+                        fn(P, Q, b, users[o:o + small], pos[o:o + small], neg[o:o + small], lr, reg)
+                    e2.record(stream)
+                    for s in range(200):
+                        o = (s % 1000) * small
+                        fn(P, Q, b, users[o:o + small], pos[o:o + small], neg[o:o + small], lr, reg)
+                    e3.record(stream)
+                    torch.cuda.synchronize()
+                    ref[name] = {"triples_per_s": 200 * small / (e2.elapsed_time(e3) * 1e-3), "us_per_step": e2.elapsed_time(e3) * 1e3 / 200}
+                out["reference_batch_512"] = ref
 
             if not args.no_eval:
                 # the trained tables are not evaluated: 400 summed-gradient steps at this batch size leave item

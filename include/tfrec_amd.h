@@ -212,6 +212,21 @@ int tfrec_bpr_grad_step(tfrec_ctx *ctx, float *d_P, float *d_Qc, float *d_bc,
                         float lr, float reg, double *d_loss);
 int tfrec_rows_sgd_apply(tfrec_ctx *ctx, float *d_Q, float *d_b, int64_t I, int d,
                          const int32_t *d_ids, const float *d_grad_rows, const float *d_grad_b, int64_t n, float lr);
+/* tfrec_bpr_grad_step on a batch whose index arrays (local user rows, item slots) were sorted ahead with
+ * tfrec_batch_prepare(slot, U, Ic, ...): the sort then runs beside the all-to-all that fetches the rows. */
+int tfrec_bpr_grad_step_prepared(tfrec_ctx *ctx, int slot, float *d_P, float *d_Qc, float *d_bc,
+                                 int64_t U, int64_t Ic, int d, float lr, float reg, double *d_loss);
+/* The requester side of the lookup: the distinct items of a batch (d_pos / d_neg, global ids below I), ascending --
+ * hence grouped by owner when owner r holds items [r * items_per_owner, (r + 1) * items_per_owner) -- in d_uniq
+ * (room for min(2B, I) ids), the slot of every triple's items in that list (d_pos_slot, d_neg_slot), the number of
+ * distinct items per owner (d_counts, int64 [n_owners]) and in all (d_n_uniq, optional).  Marks over the item
+ * range and a prefix sum, no sort; everything stays on the device.
+ * tfrec_rows_gather: the owner side: out_rows[t] = Q[ids[t]], out_b[t] = b[ids[t]] (ids local to the shard). */
+int tfrec_items_dedup(tfrec_ctx *ctx, const int32_t *d_pos, const int32_t *d_neg, int64_t B, int64_t I,
+                      int64_t items_per_owner, int n_owners, int32_t *d_uniq, int32_t *d_pos_slot, int32_t *d_neg_slot,
+                      int64_t *d_counts, int64_t *d_n_uniq);
+int tfrec_rows_gather(tfrec_ctx *ctx, const float *d_Q, const float *d_b, int64_t I, int d,
+                      const int32_t *d_ids, int64_t n, float *d_out_rows, float *d_out_b);
 
 /* The step of a GPU that holds a shard of P and a full copy of Q, b (small item tables): P is
  * updated in place; d_G = [I*d | I] floats is zeroed and receives, for every item the batch

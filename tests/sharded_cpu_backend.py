@@ -16,7 +16,20 @@ class CpuBackend:
         full = np.random.default_rng(seed).uniform(lo, hi, (row_hi, d)).astype(np.float32)
         return torch.from_numpy(full[row_lo:row_hi].copy())
 
-    def bpr_grad_step(self, P, Qc, bc, users, pos_slot, neg_slot, lr, reg):
+    def items_dedup(self, pos, neg, I, items_per_owner, n_owners, counts_out):
+        items = np.concatenate([_np(pos), _np(neg)]).astype(np.int64)
+        uniq, inv = np.unique(items, return_inverse=True)
+        B = pos.shape[0]
+        owner = uniq // items_per_owner
+        counts_out.copy_(torch.from_numpy(np.bincount(owner, minlength=n_owners).astype(np.int64)))
+        return (torch.from_numpy(uniq.astype(np.int32)), torch.from_numpy(inv[:B].astype(np.int32)), torch.from_numpy(inv[B:].astype(np.int32)))
+
+    def rows_gather(self, Q, b, ids):
+        idx = ids.to(torch.int64)
+        return Q.index_select(0, idx).contiguous(), b.index_select(0, idx).contiguous()
+
+    def bpr_grad_step(self, P, Qc, bc, users, pos_slot, neg_slot, lr, reg, slot=-1):
+        assert slot == -1, "the CPU stand-in has no prepared batches"
         P_, Q_, b_ = _np(P), _np(Qc), _np(bc)
         u, i, j = _np(users).astype(np.int64), _np(pos_slot).astype(np.int64), _np(neg_slot).astype(np.int64)
         p, qi, qj = P_[u].astype(np.float64), Q_[i].astype(np.float64), Q_[j].astype(np.float64)

@@ -389,3 +389,32 @@ def test_two_ranks_all_tables_sharded_dns_epochs_and_item_sharded_eval(tmp_path,
         np.testing.assert_allclose(rs[0][name], ref, rtol=1e-6, atol=1e-7, err_msg=name)
         assert np.array_equal(rs[0][name], rs[1][name])
     dev.close()
+
+
+@pytest.mark.parametrize("I,B,W", [(1000, 300, 3), (50000, 40000, 8), (4097, 9000, 2), (7, 5, 1)])
+def test_items_dedup_and_rows_gather(I, B, W):
+    """The requester's de-duplication (distinct items ascending, slots, per-owner counts) and the owner's row
+    gather against numpy."""
+    from tfrec_amd.device import Device
+    dev = Device(0)
+    rng = np.random.default_rng(I + B)
+    pos = (rng.zipf(1.2, B) % I).astype(np.int32)
+    neg = rng.integers(0, I, B).astype(np.int32)
+    per = (I + W - 1) // W
+    uniq, ps, ns = dev.empty(min(2 * B, I), np.int32), dev.empty(B, np.int32), dev.empty(B, np.int32)
+    counts, total = dev.empty(W, np.int64), dev.empty(1, np.int64)
+    dev.items_dedup(dev.array(pos), dev.array(neg), I, per, W, uniq, ps, ns, counts, total)
+    dev.synchronize()
+    want, inv = np.unique(np.concatenate([pos, neg]), return_inverse=True)
+    n = int(total.numpy()[0])
+    assert n == len(want) and np.array_equal(uniq.numpy()[:n], want)
+    assert np.array_equal(ps.numpy(), inv[:B]) and np.array_equal(ns.numpy(), inv[B:])
+    assert np.array_equal(counts.numpy(), np.bincount(want // per, minlength=W))
+    d = 20
+    Q = rng.standard_normal((I, d)).astype(np.float32)
+    b = rng.standard_normal(I).astype(np.float32)
+    rows, bias = dev.empty((n, d), np.float32), dev.empty(n, np.float32)
+    dev.rows_gather(dev.array(Q), dev.array(b), dev.array(want.astype(np.int32)), rows, bias)
+    dev.synchronize()
+    assert np.array_equal(rows.numpy(), Q[want]) and np.array_equal(bias.numpy(), b[want])
+    dev.close()

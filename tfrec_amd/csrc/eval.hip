@@ -497,8 +497,14 @@ struct ScoreWave { static constexpr int UW = 1, NW = 4; };
 // synthetic ones, bf16 d=128 with lists of 256 a further +4 %; f32 d=64 loses 3 % and stays at eight.
 template <int CAP>
 struct ScoreWave<64, true, CAP> { static constexpr int UW = 1, NW = 16; };   // 125 registers: sixteen waves fit a CU
+#ifndef TF_SW128_UW
+#define TF_SW128_UW 1
+#endif
+#ifndef TF_SW128_NW
+#define TF_SW128_NW 16
+#endif
 template <int CAP>
-struct ScoreWave<128, true, CAP> { static constexpr int UW = 1, NW = CAP <= 256 ? 16 : 8; };
+struct ScoreWave<128, true, CAP> { static constexpr int UW = CAP <= 256 ? TF_SW128_UW : 1, NW = CAP <= 256 ? TF_SW128_NW : 8; };
 template <int CAP>
 struct ScoreWave<256, true, CAP> { static constexpr int UW = 1, NW = 8; };
 template <int CAP>
@@ -514,8 +520,10 @@ struct ScoreGeom {
     // items per step; a workgroup of sixteen waves is alone on its CU and takes tiles three times as long (a third of
     // the barriers) where the CU's 160 KB hold two of them beside the sort buffers, else twice as long
     static constexpr int TI0 = D * ESZ >= 256 ? 64 : 128;
-    static constexpr int TI = ScoreWave<D, BF16, CAP>::NW != 16 ? TI0
-                              : (score_lds_bytes(3 * TI0, ROWB, 16, CAP) <= 160 * 1024 ? 3 * TI0 : 2 * TI0);
+    static constexpr bool ALONE = ScoreWave<D, BF16, CAP>::NW == 16 || ScoreWave<D, BF16, CAP>::UW > 1;   // one workgroup per CU
+    static constexpr int TI = !ALONE ? TI0
+                              : (score_lds_bytes(3 * TI0, ROWB, ScoreWave<D, BF16, CAP>::NW, CAP) <= 160 * 1024 &&
+                                 (3 * TI0 * (D * ESZ / 16)) % (64 * ScoreWave<D, BF16, CAP>::NW) == 0 ? 3 * TI0 : 2 * TI0);
     static constexpr int CPR = D * ESZ / 16;                 // 16-byte chunks per row
     static constexpr int NW = ScoreWave<D, BF16, CAP>::NW, NT = 64 * NW;   // waves / threads per workgroup
     static constexpr int NLD = TI * CPR / NT;                // chunks per thread per tile

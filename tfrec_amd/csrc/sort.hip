@@ -233,6 +233,43 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(Src src,
     }
 }
 
+// Small batches (the reference's 512 or 128 triples a step): the radix passes above are nine launches that finish
+// in microseconds each, so a step is bound by its launches.  Up to SMALL_MAX pairs are sorted by ONE workgroup
+// instead: (key, value) words in LDS, bitonic network.  Ordering by the 64-bit word equals the stable order by key
+// because the values of a training batch ascend in input order (occurrence ids).
+constexpr int SMALL_MAX = 8192;
+
+template <class Src>
+__global__ __launch_bounds__(1024) void sort_small_kernel(Src src, uint32_t n, uint32_t npad, uint32_t *__restrict__ kout,
+                                                          uint32_t *__restrict__ vout)
+{
+    __shared__ uint64_t e[SMALL_MAX];
+    bool bad = false;
+    for (uint32_t i = threadIdx.x; i < npad; i += 1024) {
+        uint32_t k = 0, v = 0;
+        src.load(i < n ? i : n - 1, k, v, bad);
+        e[i] = i < n ? ((uint64_t)k << 32) | v : ~0ull;
+    }
+    src.report(bad);
+    __syncthreads();
+    for (uint32_t k2 = 2; k2 <= npad; k2 <<= 1) {
+        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < npad / 2; t += 1024) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+                const uint64_t a = e[i], b = e[p];
+                const bool up = (i & k2) == 0;
+                if ((a > b) == up) { e[i] = b; e[p] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        const uint64_t w = e[i];
+        kout[i] = (uint32_t)(w >> 32);
+        vout[i] = (uint32_t)w;
+    }
+}
+
 constexpr int SORT_RB_MAX = TF_SORT_RB_MAX;      // widest digit
 
 // Pairs per lane: tiles of 4096 pairs move data best; below about a million pairs there are too few
@@ -303,6 +340,13 @@ int sort_run(void *d_temp, size_t temp_bytes, const TripleSrc *first_src, const 
     if (n == 0) return TFREC_OK;
     TF_REQUIRE(n < (1ull << 32), TFREC_EUNSUP, "sort of %zu pairs: positions must fit 32 bits", n);
     TF_REQUIRE(end_bit >= 1 && end_bit <= 32, TFREC_EINVAL, "sort key width %d out of range", end_bit);
+    if (first_src && n <= (size_t)SMALL_MAX) {
+        uint32_t npad = 2;
+        while (npad < n) npad <<= 1;
+        sort_small_kernel<TripleSrc><<<1, 1024, 0, stream>>>(*first_src, (uint32_t)n, npad, keys_out, vals_out);
+        TF_HIP(hipGetLastError());
+        return TFREC_OK;
+    }
     const SortPlan p = sort_plan(n, end_bit);
     TF_REQUIRE(temp_bytes >= p.counts_bytes + p.total_bytes + 2 * p.tmp_bytes, TFREC_EINVAL, "internal: sort scratch too small");
     char *t = (char *)d_temp;

@@ -1074,7 +1074,7 @@ extern "C" int tfrec_batch_prepare_many(tfrec_ctx *ctx, int slot, int64_t U, int
 }
 
 static int step_prepared_impl(tfrec_ctx *ctx, int slot, float *d_P, float *d_Q, float *d_b, int64_t U, int64_t I, int d, float lr,
-                              float reg, double *d_loss, const tfrec_utable *ut)
+                              float reg, double *d_loss, const tfrec_utable *ut, bool item_grad_only = false)
 {
     TF_REQUIRE(slot == 0 || slot == 1, TFREC_EINVAL, "slot must be 0 or 1");
     tfrec_batch_slot &sl = ctx->slots[slot];
@@ -1084,7 +1084,7 @@ static int step_prepared_impl(tfrec_ctx *ctx, int slot, float *d_P, float *d_Q, 
     TF_HIP(hipStreamWaitEvent(ctx->stream, sl.ready, 0));
     tfrec_marks_reset(ctx);
     tfrec_mark(ctx, "start");
-    const int rc = bpr_passes(ctx, sl, d_P, d_Q, d_b, U, d, lr, reg, d_loss, false, nullptr, nullptr, ut);
+    const int rc = bpr_passes(ctx, sl, d_P, d_Q, d_b, U, d, lr, reg, d_loss, item_grad_only, nullptr, nullptr, ut);
     if (++sl.next_k >= sl.K) {      // the last batch of the slot: its arrays may be overwritten once this step is done
         TF_HIP(hipEventRecord(sl.released, ctx->stream));
         sl.has_released = true;
@@ -1098,6 +1098,13 @@ extern "C" int tfrec_bpr_sgd_step_prepared(tfrec_ctx *ctx, int slot, float *d_P,
 {
     TF_TRY(tfrec_ctx_enter(ctx));
     return step_prepared_impl(ctx, slot, d_P, d_Q, d_b, U, I, d, lr, reg, d_loss, nullptr);
+}
+
+extern "C" int tfrec_bpr_grad_step_prepared(tfrec_ctx *ctx, int slot, float *d_P, float *d_Qc, float *d_bc, int64_t U, int64_t Ic, int d,
+                                            float lr, float reg, double *d_loss)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    return step_prepared_impl(ctx, slot, d_P, d_Qc, d_bc, U, Ic, d, lr, reg, d_loss, nullptr, true);
 }
 
 extern "C" int tfrec_bpr_sgd_step_prepared_v(tfrec_ctx *ctx, int slot, tfrec_utable *t, float *d_Q, float *d_b, int64_t I, float lr,

@@ -306,6 +306,25 @@ class Device:
         _lib.check(self.lib.tfrec_bpr_grad_step(self.h, _ptr(P), _ptr(Qc), _ptr(bc), U, Ic, d, _ptr(users), _ptr(pos_slot),
                                                 _ptr(neg_slot), B, float(lr), float(reg), _ptr(loss)))
 
+    def bpr_grad_step_prepared(self, slot, P, Qc, bc, lr, reg, loss=None):
+        """``bpr_grad_step`` on a batch sorted ahead with ``prepare_batch(slot, U, Ic, users, pos_slot, neg_slot)``."""
+        U, d = _shape(P)
+        Ic = _shape(Qc)[0]
+        _lib.check(self.lib.tfrec_bpr_grad_step_prepared(self.h, int(slot), _ptr(P), _ptr(Qc), _ptr(bc), U, Ic, d, float(lr), float(reg),
+                                                         _ptr(loss)))
+
+    def items_dedup(self, pos, neg, I, items_per_owner, n_owners, uniq, pos_slot, neg_slot, counts, n_uniq=None):
+        """Distinct items of a batch (ascending), every triple's slots in that list, distinct items per owner."""
+        B = _shape(pos)[0]
+        _lib.check(self.lib.tfrec_items_dedup(self.h, _ptr(pos), _ptr(neg), B, int(I), int(items_per_owner), int(n_owners), _ptr(uniq),
+                                              _ptr(pos_slot), _ptr(neg_slot), _ptr(counts), _ptr(n_uniq)))
+
+    def rows_gather(self, Q, b, ids, out_rows, out_b):
+        """out_rows[t] = Q[ids[t]], out_b[t] = b[ids[t]]."""
+        I, d = _shape(Q)
+        n = _shape(ids)[0]
+        _lib.check(self.lib.tfrec_rows_gather(self.h, _ptr(Q), _ptr(b), I, d, _ptr(ids), n, _ptr(out_rows), _ptr(out_b)))
+
     def bpr_dense_grad_step(self, P, Q, b, G, users, pos, neg, lr, reg, slot=-1, loss=None):
         """Step of a GPU holding a P shard and a full Q, b copy: P updated in place, the flat table
         ``G`` ([I*d | I] floats) zeroed and filled with the gradient sums of the touched items.

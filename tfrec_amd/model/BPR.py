@@ -42,17 +42,31 @@ class BPR(AbstractRecommender):
         return DataIterator(np.concatenate(users), np.concatenate(pos_items), np.concatenate(neg_items),
                             batch_size=self.batch_size, shuffle=True)
 
-    def _train_epoch(self, train_data):
-        """One epoch of minibatch steps (model/BPR.py:68-72): the epoch's triples are uploaded once
-        in batch order and every batch is one tfrec_bpr_sgd_step on a slice of them."""
-        (users, pos, neg), bounds = train_data.columns_in_epoch_order()
+    # batches from this size on run on a versioned user table (no staging of pre-step user rows); below it a step
+    # is bound by its kernel launches and the plain table saves one
+    VERSIONED_FROM = 1 << 16
+
+    def _run_steps(self, du, dp, dn, bounds):
+        """The minibatch steps of one epoch (model/BPR.py:68-72) over device arrays in batch order."""
         dev = self.sess
-        du, dp, dn = dev.array(users, np.int32), dev.array(pos, np.int32), dev.array(neg, np.int32)
         P, Q, b = self.mf.device_parameters()
+        ut = dev.user_table(P) if self.batch_size >= self.VERSIONED_FROM else None
         for k in range(len(bounds) - 1):
             lo, hi = bounds[k], bounds[k + 1]
-            dev.bpr_sgd_step(P, Q, b, du.view(lo, hi), dp.view(lo, hi), dn.view(lo, hi), self.lr, self.reg)
+            if ut is not None:
+                dev.bpr_sgd_step_v(ut, Q, b, du.view(lo, hi), dp.view(lo, hi), dn.view(lo, hi), self.lr, self.reg)
+            else:
+                dev.bpr_sgd_step(P, Q, b, du.view(lo, hi), dp.view(lo, hi), dn.view(lo, hi), self.lr, self.reg)
+        if ut is not None:
+            ut.close()              # P is complete again for the evaluation that follows
         dev.synchronize()
+
+    def _train_epoch(self, train_data):
+        """One epoch of minibatch steps (model/BPR.py:68-72): the epoch's triples are uploaded once
+        in batch order and every batch is one step on a slice of them."""
+        (users, pos, neg), bounds = train_data.columns_in_epoch_order()
+        dev = self.sess
+        self._run_steps(dev.array(users, np.int32), dev.array(pos, np.int32), dev.array(neg, np.int32), bounds)
 
     def _device_epoch(self, epoch):
         """Device arrays (users, pos, neg) of the epoch, shuffled."""
@@ -60,14 +74,9 @@ class BPR(AbstractRecommender):
 
     def _train_epoch_on_device(self, epoch):
         """The same epoch with the triples drawn, shuffled and consumed on the GPU."""
-        dev = self.sess
         users, pos, neg = self._device_epoch(epoch)
-        P, Q, b = self.mf.device_parameters()
         n = self._device_sampler.nnz
-        for lo in range(0, n, self.batch_size):
-            hi = min(lo + self.batch_size, n)
-            dev.bpr_sgd_step(P, Q, b, users.view(lo, hi), pos.view(lo, hi), neg.view(lo, hi), self.lr, self.reg)
-        dev.synchronize()
+        self._run_steps(users, pos, neg, list(range(0, n, self.batch_size)) + [n])
 
     def train_model(self):
         self.logger.info(self.evaluator.metrics_info())

@@ -100,8 +100,28 @@ class HipBackend:
     def __init__(self, dev):
         self.dev = dev
 
-    def bpr_grad_step(self, P, Qc, bc, users, pos_slot, neg_slot, lr, reg):
-        self.dev.bpr_grad_step(P, Qc, bc, users, pos_slot, neg_slot, lr, reg)
+    def bpr_grad_step(self, P, Qc, bc, users, pos_slot, neg_slot, lr, reg, slot=-1):
+        if slot >= 0:
+            self.dev.bpr_grad_step_prepared(slot, P, Qc, bc, lr, reg)
+        else:
+            self.dev.bpr_grad_step(P, Qc, bc, users, pos_slot, neg_slot, lr, reg)
+
+    def items_dedup(self, pos, neg, I, items_per_owner, n_owners, counts_out):
+        """(uniq buffer, pos_slot, neg_slot): the distinct items of a batch, ascending, in the first sum(counts) entries
+        of the buffer; ``counts_out`` (device int64[n_owners]) receives the distinct items per owner."""
+        B = pos.shape[0]
+        uniq = torch.empty(max(min(2 * B, I), 1), dtype=torch.int32, device=pos.device)
+        ps, ns = torch.empty(B, dtype=torch.int32, device=pos.device), torch.empty(B, dtype=torch.int32, device=pos.device)
+        self.dev.items_dedup(pos, neg, I, items_per_owner, n_owners, uniq, ps, ns, counts_out)
+        return uniq, ps, ns
+
+    def rows_gather(self, Q, b, ids):
+        n = ids.shape[0]
+        rows = torch.empty((n, Q.shape[1]), dtype=torch.float32, device=Q.device)
+        bias = torch.empty(n, dtype=torch.float32, device=Q.device)
+        if n:
+            self.dev.rows_gather(Q, b, ids, rows, bias)
+        return rows, bias
 
     def rows_sgd_apply(self, Q, b, ids, grad_rows, grad_b, lr):
         self.dev.rows_sgd_apply(Q, b, ids, grad_rows, grad_b, lr)
@@ -307,51 +327,61 @@ class ShardedBprTrainer:
         self.backend.axpy(self._Qb, self._G, -self.lr)
 
     def step(self, users, pos, neg):
-        """One global minibatch step; collective: every rank must call it (an empty batch is allowed)."""
+        """One global minibatch step; collective: every rank must call it (an empty batch is allowed).  With a
+        sharded item table this plans the exchange of just this batch (one host synchronisation for the
+        counts); ``plan_steps`` + ``step_planned`` plan many steps at once and then run them without any."""
         if self.item_mode == "dense":
             return self._dense_step(users, pos, neg, -1)
-        dev, W = self.device, self.world
-        users = users.to(torch.int32)
-        B = users.shape[0]
-        items = torch.cat([pos, neg]).to(torch.int64)
-        # (1) distinct items of this rank's batch, ascending (hence grouped by owner), without a sort:
-        #     presence marks over the item range, a prefix sum for the slots, a compaction for the ids
-        if self._mark is None:
-            self._mark = torch.zeros(self.I, dtype=torch.int32, device=dev)
-        mark = self._mark
-        mark.zero_()
-        mark.index_fill_(0, items, 1)
-        rank = torch.cumsum(mark, 0, dtype=torch.int32)
-        uniq = torch.nonzero(mark).squeeze(1)
-        slots = rank.index_select(0, items) - 1
-        pos_slot, neg_slot = slots[:B].contiguous(), slots[B:].contiguous()
-        ends = torch.clamp(torch.arange(1, W + 1, device=dev, dtype=torch.int64) * self.ipr, max=self.I) - 1
-        upto = rank.index_select(0, ends).to(torch.int64)                 # distinct items below each owner's upper bound
-        send_counts = upto - torch.cat([upto.new_zeros(1), upto[:-1]])
-        # (2) how many ids each owner will be asked for
+        self.step_planned(self.plan_steps([(users, pos, neg)])[0])
+
+    def plan_steps(self, batches):
+        """Plans the lookups of a list of upcoming steps (collective).  ``batches``: this rank's (users, pos, neg)
+        per step, global ids, every user inside ``user_range``; empty batches allowed.  Per step the library
+        de-duplicates the items (marks + prefix sum, ascending, hence grouped by owner) and counts them per owner;
+        ALL the counts cross in one all-to-all and are read back once, so that the steps themselves
+        (``step_planned``) know every message size without touching the host again."""
+        assert self.item_mode == "sharded"
+        W, dev = self.world, self.device
+        S = len(batches)
+        counts = torch.zeros((S, W), dtype=torch.int64, device=dev)
+        plans = []
+        for s, (users, pos, neg) in enumerate(batches):
+            users = (users.to(torch.int32) - self.user_range[0]).contiguous()
+            pos, neg = pos.to(torch.int32).contiguous(), neg.to(torch.int32).contiguous()
+            uniq, ps, ns = self.backend.items_dedup(pos, neg, self.I, self.ipr, W, counts[s])
+            plans.append({"B": int(users.shape[0]), "users": users, "pos_slot": ps, "neg_slot": ns, "uniq": uniq})
         if W > 1:
-            recv_counts = torch.empty_like(send_counts)
-            _all_to_all_rows(recv_counts, send_counts, [1] * W, [1] * W, self.group)
+            asked = torch.empty((W, S), dtype=torch.int64, device=dev)          # row r: what rank r asks of me, per step
+            _all_to_all_rows(asked, counts.t().contiguous(), [1] * W, [1] * W, self.group)
         else:
-            recv_counts = send_counts.clone()
-        sc, rc = send_counts.tolist(), recv_counts.tolist()
-        want = self._a2a(uniq.to(torch.int32), sc, rc)                  # ids the others want from me (global)
-        local = (want.to(torch.int64) - self.item_range[0])
-        # (3) my rows for them: [row | bias]
-        payload = torch.cat([self.Q.index_select(0, local), self.b.index_select(0, local).unsqueeze(1)], dim=1)
-        got = self._a2a(payload, rc, sc)                                # rows of my distinct items, in uniq order
-        Qc = got[:, :self.d].contiguous()
-        bc = got[:, self.d].contiguous()
-        # (4) local step: P shard updated in place, Qc/bc turned into gradient sums
+            asked = counts.t().contiguous()
+        both = torch.stack([counts, asked.t().contiguous()]).cpu()           # the one host read of the plan
+        for s, p in enumerate(plans):
+            p["send"], p["recv"] = both[0, s].tolist(), both[1, s].tolist()
+            p["uniq"] = p["uniq"][: sum(p["send"])]
+        return plans
+
+    def step_planned(self, plan, slot=0):
+        """One global minibatch step from a plan of ``plan_steps``: no host synchronisation.  The batch's index sort
+        runs on the library's auxiliary stream beside the all-to-all that fetches the rows."""
+        be, sc, rc = self.backend, plan["send"], plan["recv"]
+        B, n_uniq = plan["B"], sum(plan["send"])
+        nu = self.user_range[1] - self.user_range[0]
+        ahead = B > 0 and hasattr(be, "prepare_batch")
+        if ahead:
+            be.prepare_batch(slot, nu, n_uniq, plan["users"], plan["pos_slot"], plan["neg_slot"])
+        # (1) ids to their owners, (2) the owners' rows and biases back, in the order of plan["uniq"]
+        want = self._a2a(plan["uniq"], sc, rc)
+        local = (want - self.item_range[0]).contiguous()
+        rows, bias = be.rows_gather(self.Q, self.b, local)
+        Qc, bc = self._a2a(rows, rc, sc), self._a2a(bias, rc, sc)
+        # (3) local step: P shard updated in place, Qc / bc turned into gradient sums
         if B > 0:
-            self.backend.bpr_grad_step(self.P, Qc, bc, (users - self.user_range[0]).contiguous(), pos_slot, neg_slot, self.lr, self.reg)
-        else:
-            Qc.zero_(); bc.zero_()
-        # (5) gradient sums back to the owners, (6) owners reduce in rank order and apply
-        grads = self._a2a(torch.cat([Qc, bc.unsqueeze(1)], dim=1), sc, rc)
-        if grads.shape[0] > 0:
-            self.backend.rows_sgd_apply(self.Q, self.b, local.to(torch.int32).contiguous(), grads[:, :self.d].contiguous(),
-                                        grads[:, self.d].contiguous(), self.lr)
+            be.bpr_grad_step(self.P, Qc, bc, plan["users"], plan["pos_slot"], plan["neg_slot"], self.lr, self.reg, slot=slot if ahead else -1)
+        # (4) gradient sums back to the owners, who add them in rank order and apply
+        gr, gb = self._a2a(Qc, sc, rc), self._a2a(bc, sc, rc)
+        if local.shape[0] > 0:
+            be.rows_sgd_apply(self.Q, self.b, local, gr, gb, self.lr)
 
     def full_item_table(self):
         """(Q, b) of ALL items on this rank: the local copy (replicated table) or an all-gather of the
@@ -609,7 +639,16 @@ class ShardedEpochSampler:
         steps = torch.tensor([(self.nnz + batch_size - 1) // batch_size], dtype=torch.int64, device=t.device)
         if t.world > 1:
             _all_reduce(steps, t.group, op=dist.ReduceOp.MAX)
-        for s in range(int(steps.item())):
+        n_steps = int(steps.item())
+        batches = []
+        for s in range(n_steps):
             lo, hi = min(s * batch_size, self.nnz), min((s + 1) * batch_size, self.nnz)
-            t.step(users[lo:hi], pos[lo:hi], neg[lo:hi])
-        return int(steps.item())
+            batches.append((users[lo:hi], pos[lo:hi], neg[lo:hi]))
+        if t.item_mode == "sharded":
+            # every message size of the epoch is settled here, in one exchange and one host read
+            for k, plan in enumerate(t.plan_steps(batches)):
+                t.step_planned(plan, slot=k & 1)
+        else:
+            for b in batches:
+                t.step(*b)
+        return n_steps
