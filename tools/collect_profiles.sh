@@ -1,13 +1,23 @@
-# Developer script (run on the GPU box from the repository root): kernel stats and the two counter
-# passes of the bench workload, outputs under gpurun_out/.
+# Developer script (run on the GPU box from the repository root): kernel stats and the counter passes of the
+# bench workload and of the scoring kernel, outputs under gpurun_out/ (TAG names the round, e.g. r2).
 set -e
 R=$GRAFT_REPO_ROOT
+TAG=${TAG:-r2}
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 python3 $R/bench.py > $R/gpurun_out/bench.json 2> $R/gpurun_out/bench.err
+timeout -k 10 600 python3 $R/bench.py > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err
 echo "bench done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/prof_stats.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof_stats -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${TAG}_prof_stats.log 2>&1
 echo "stats done"
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-eval --no-cpu-baseline --no-other > $R/gpurun_out/pmc_fetch.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-eval --no-cpu-baseline --no-other --no-extras > $R/gpurun_out/${TAG}_pmc_fetch.log 2>&1
 echo "fetch done"
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-eval --no-cpu-baseline --no-other > $R/gpurun_out/pmc_write.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-eval --no-cpu-baseline --no-other --no-extras > $R/gpurun_out/${TAG}_pmc_write.log 2>&1
 echo "write done"
+# scoring kernel at the 2M-item, d=128, k=100 shape, independent factors: matrix-pipe and vector-pipe busy cycles,
+# wave cycles, and (own pass) the clock the chip held
+EA="--users 262144 --U 262144 --I 2000000 --d 128 --k 100 --model random --mode bf16 --reps 1"
+timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU --output-format csv -d $R/gpurun_out/${TAG}_pmc_eval1 -- python3 $R/tools/eval_probe.py $EA > $R/gpurun_out/${TAG}_pmc_eval1.log 2>&1
+echo "eval pass 1 done"
+timeout -s KILL 200 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/${TAG}_pmc_eval2 -- python3 $R/tools/eval_probe.py $EA > $R/gpurun_out/${TAG}_pmc_eval2.log 2>&1
+echo "eval pass 2 done"
+timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/gpurun_out/${TAG}_pmc_eval3 -- python3 $R/tools/eval_probe.py $EA > $R/gpurun_out/${TAG}_pmc_eval3.log 2>&1 || echo "eval pass 3 failed (counter names)"
+echo "eval pass 3 done"

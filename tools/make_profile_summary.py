@@ -7,6 +7,9 @@ gpurun_out/ (developer tool).
   pmc_fetch / pmc_write: rocprofv3 --pmc FETCH_SIZE (WRITE_SIZE) --output-format csv -- python3 bench.py --steps 5 --warmup 2
                          --no-eval --no-cpu-baseline --no-other   (one pass each)
   bench.json: the JSON line of an un-profiled default run
+  optional, after those: the three counter passes of tools/collect_profiles.sh over the scoring kernel
+  (tools/eval_probe.py at the 2M-item, d=128, k=100 shape): eval1 (SQ busy / wave cycles), eval2 (GRBM_GUI_ACTIVE),
+  eval3 (instruction and LDS counters)
 """
 import collections
 import csv
@@ -15,7 +18,7 @@ import os
 import shutil
 import sys
 
-STEP_KERNELS = ("seg_tile_kernel", "seg_fixup_kernel", "build_keys_kernel", "sort_hist_kernel", "sort_scan_kernel", "sort_scatter_kernel",
+STEP_KERNELS = ("seg_tile_kernel", "seg_fixup_kernel", "utable_flip_kernel", "sort_hist_kernel", "sort_scan_kernel", "sort_scatter_kernel",
                 "loss_finalize")
 # FETCH_SIZE (KiB) counts memory-side read requests at 64 bytes each.  Streaming reads issue one 128-byte
 # request per line (bytes = 2 x FETCH_SIZE x 1024, the microarchitecture guide's correction); gathers of
@@ -41,6 +44,51 @@ def short(name):
                     pol = "<" + p + ">"
             return k + pol
     return None
+
+
+def eval_section(d1, d2, d3):
+    """Matrix-pipe utilisation of score_topk_kernel from the SQ counters (sums over all dispatches of the passes)."""
+    def sums(d):
+        a, dur, seen = collections.defaultdict(float), 0, set()
+        for r in csv.DictReader(open(find(d, "counter_collection.csv"))):
+            if "score_topk_kernel" in r["Kernel_Name"]:
+                a[r["Counter_Name"]] += float(r["Counter_Value"])
+                if r["Dispatch_Id"] not in seen:
+                    seen.add(r["Dispatch_Id"])
+                    dur += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        return a, dur / 1e9, len(seen)
+    a1, t1, n1 = sums(d1)
+    a2, t2, n2 = sums(d2)
+    a3, t3, n3 = sums(d3)
+    n_simd, n_cu, n_xcd = 1024, 256, 8
+    cyc = a2["GRBM_GUI_ACTIVE"] / n_xcd                      # shader cycles over the pass's dispatches (the counter sums the XCDs)
+    clock = cyc / t2 / 1e9
+    busy = a1["SQ_VALU_MFMA_BUSY_CYCLES"] / (n_simd * cyc * t1 / t2)
+    users, items, d = 262144, 2_000_000, 128
+    flops = 2.0 * users * items * d * n1
+    out = ["## Scoring kernel: matrix-pipe utilisation (PMC)", "",
+           "`tools/eval_probe.py --users 262144 --I 2000000 --d 128 --k 100 --model random --mode bf16` (independent factors) under",
+           "`rocprofv3 --pmc` in three passes (`tools/collect_profiles.sh`); sums over the %d dispatches of `score_topk_kernel<128, bf16, 256>` in a pass." % n1, "",
+           "| quantity | value |", "|---|---|",
+           "| kernel time per dispatch | %.1f ms |" % (t1 / n1 * 1e3),
+           "| clock held (GRBM_GUI_ACTIVE / 8 XCDs / time) | %.2f GHz |" % clock,
+           "| SQ_INSTS_MFMA per dispatch | %.4g (expected users/32 x items/32 x d/16 = %.4g) |" % (a3["SQ_INSTS_MFMA"] / n3, users / 32 * items / 32 * d / 16),
+           "| SQ_VALU_MFMA_BUSY_CYCLES per dispatch | %.4g (= 32 cycles per `v_mfma_f32_32x32x16_bf16`) |" % (a1["SQ_VALU_MFMA_BUSY_CYCLES"] / n1),
+           "| **matrix-pipe busy = MFMA busy cycles / (1024 SIMDs x elapsed shader cycles)** | **%.1f %%** |" % (100 * busy),
+           "| achieved | %.0f TFLOP/s = %.1f %% of the 2.5 PFLOP/s nominal peak (2.4 GHz), %.1f %% of the peak at the clock held |" % (
+               flops / t1 / 1e12, 100 * flops / t1 / 2.5e15, 100 * flops / t1 / (2.5e15 * clock / 2.4)),
+           "| CU busy (SQ_BUSY_CU_CYCLES / 256 CUs / cycles) | %.0f %% |" % (100 * a1["SQ_BUSY_CU_CYCLES"] / (n_cu * cyc * t1 / t2)),
+           "| LDS array active (SQ_LDS_IDX_ACTIVE / 256 CUs / cycles) | %.0f %%, bank conflicts %.3g |" % (
+               100 * a3["SQ_LDS_IDX_ACTIVE"] / (n_cu * cyc * t3 / t2), a3["SQ_LDS_BANK_CONFLICT"]),
+           "| wave cycles: waiting (SQ_WAIT_ANY) / issue-stalled (SQ_WAIT_INST_ANY) | %.0f %% / %.0f %% of SQ_WAVE_CYCLES |" % (
+               100 * a1["SQ_WAIT_ANY"] / a1["SQ_WAVE_CYCLES"], 100 * a1["SQ_WAIT_INST_ANY"] / a1["SQ_WAVE_CYCLES"]),
+           "| vector instructions per matrix instruction | %.1f |" % (a1["SQ_INSTS_VALU"] / a3["SQ_INSTS_MFMA"] * n3 / n1), ""]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    json.dump({"kernel": "score_topk_kernel<128, bf16, 256>", "workload": "262144 users x 2M items, d=128, k=100, independent factors",
+               "mfma_busy_frac": busy, "clock_ghz": clock, "tflops": flops / t1 / 1e12,
+               "source": "rocprofv3 --pmc passes of tools/collect_profiles.sh"},
+              open(os.path.join(root, "profiles", "pmc_mfma.json"), "w"), indent=1)
+    return out
 
 
 def main():
@@ -95,6 +143,8 @@ def main():
                 tot_guide, tot_cal, tot_w, tot_cal + tot_w),
             "Algorithmic bytes per step: %d x %d = %.0f MB, so measured traffic is %.2fx algorithmic (calibrated; %.2fx with the guide's x2)." % (
                 B, rf["algorithmic_bytes_per_triple"], alg, (tot_cal + tot_w) / alg, (tot_guide + tot_w) / alg), ""]
+    if len(sys.argv) >= 9:
+        out += eval_section(sys.argv[6], sys.argv[7], sys.argv[8])
     json.dump({"workload_batch": B, "factors": line["config"]["factors"],
                "bytes_per_step": (tot_cal + tot_w) * 1e6, "bytes_per_step_guide_x2": (tot_guide + tot_w) * 1e6,
                "fetched_bytes_per_step": tot_cal * 1e6, "written_bytes_per_step": tot_w * 1e6,
