@@ -37,7 +37,7 @@ __device__ __forceinline__ uint32_t clamp_index(int32_t v, uint32_t n, bool *bad
 // ------------------------------------------------------------------------------------------
 // occurrences whose gathers a lane group keeps in flight (tile sizes are multiples of these)
 #ifndef TF_DEPTH_USER
-#define TF_DEPTH_USER 8
+#define TF_DEPTH_USER 4
 #endif
 #ifndef TF_DEPTH_ITEM
 #define TF_DEPTH_ITEM 4
