@@ -55,7 +55,9 @@ struct PlainSrc {
     __device__ __forceinline__ void report(bool) const {}
 };
 
-struct TripleSrc {
+// MULTI: several batches sorted together (a batch number above the row id in every key)
+template <bool MULTI>
+struct TripleSrcT {
     tfrec_triple_src a;
     // WRITE: the scatter pass (which sees every pair exactly once) leaves the checked items in `pair`
     template <bool WRITE>
@@ -69,10 +71,13 @@ struct TripleSrc {
         const uint32_t lim = is_user ? a.U : a.I;
         bad = bad || x < 0 || (uint32_t)x >= lim;
         const uint32_t c = x < 0 ? 0u : ((uint32_t)x >= lim ? lim - 1 : (uint32_t)x);
-        // batch number t / B without a division: multiply by the rounded-up reciprocal, step back if that overshot
-        uint32_t k = a.inv_B ? __umulhi(t, a.inv_B) : 0u;
-        k -= (k * a.B > t) ? 1u : 0u;
-        const uint32_t tau = t - k * a.B;
+        uint32_t k = 0, tau = t;
+        if constexpr (MULTI) {
+            // batch number t / B without a division: multiply by the rounded-up reciprocal, step back if that overshot
+            k = __umulhi(t, a.inv_B);
+            k -= (k * a.B > t) ? 1u : 0u;
+            tau = t - k * a.B;
+        }
         key_ = (k << a.kb) | (is_user ? c : a.U + c);
         val_ = is_user ? tau : 2 * tau + side;
         if constexpr (WRITE) if (!is_user) a.pair[e] = c;
@@ -334,7 +339,7 @@ int sort_pass_rb(int rb, int items, const Src &src, uint32_t *kout, uint32_t *vo
 }
 
 // first_src: where the first pass reads its pairs (null: keys_in / vals_in)
-int sort_run(void *d_temp, size_t temp_bytes, const TripleSrc *first_src, const uint32_t *keys_in, const uint32_t *vals_in,
+int sort_run(void *d_temp, size_t temp_bytes, const tfrec_triple_src *first_src, const uint32_t *keys_in, const uint32_t *vals_in,
              uint32_t *keys_out, uint32_t *vals_out, size_t n, int end_bit, hipStream_t stream)
 {
     if (n == 0) return TFREC_OK;
@@ -343,7 +348,8 @@ int sort_run(void *d_temp, size_t temp_bytes, const TripleSrc *first_src, const 
     if (first_src && n <= (size_t)SMALL_MAX) {
         uint32_t npad = 2;
         while (npad < n) npad <<= 1;
-        sort_small_kernel<TripleSrc><<<1, 1024, 0, stream>>>(*first_src, (uint32_t)n, npad, keys_out, vals_out);
+        if (first_src->inv_B) sort_small_kernel<TripleSrcT<true>><<<1, 1024, 0, stream>>>(TripleSrcT<true>{*first_src}, (uint32_t)n, npad, keys_out, vals_out);
+        else sort_small_kernel<TripleSrcT<false>><<<1, 1024, 0, stream>>>(TripleSrcT<false>{*first_src}, (uint32_t)n, npad, keys_out, vals_out);
         TF_HIP(hipGetLastError());
         return TFREC_OK;
     }
@@ -363,7 +369,10 @@ int sort_run(void *d_temp, size_t temp_bytes, const TripleSrc *first_src, const 
         const int bits = end_bit - shift < p.rb ? end_bit - shift : p.rb;
         const uint32_t dmask = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
         int rc;
-        if (pass == 0 && first_src) rc = sort_pass_rb<TripleSrc>(p.rb, p.items, *first_src, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream);
+        if (pass == 0 && first_src && first_src->inv_B)
+            rc = sort_pass_rb<TripleSrcT<true>>(p.rb, p.items, TripleSrcT<true>{*first_src}, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream);
+        else if (pass == 0 && first_src)
+            rc = sort_pass_rb<TripleSrcT<false>>(p.rb, p.items, TripleSrcT<false>{*first_src}, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream);
         else rc = sort_pass_rb<PlainSrc>(p.rb, p.items, PlainSrc{kin, vin}, ko, vo, (uint32_t)n, shift, dmask, counts, totals, p.nblk, stream);
         if (rc != TFREC_OK) return rc;
         kin = ko; vin = vo;
@@ -388,8 +397,7 @@ int tfrec_sort_pairs(void *d_temp, size_t temp_bytes, const uint32_t *keys_in, u
 int tfrec_sort_triples(void *d_temp, size_t temp_bytes, const tfrec_triple_src &src, uint32_t *keys_out, uint32_t *vals_out,
                        int end_bit, hipStream_t stream)
 {
-    const TripleSrc ts{src};
-    return sort_run(d_temp, temp_bytes, &ts, nullptr, nullptr, keys_out, vals_out, (size_t)3 * src.n, end_bit, stream);
+    return sort_run(d_temp, temp_bytes, &src, nullptr, nullptr, keys_out, vals_out, (size_t)3 * src.n, end_bit, stream);
 }
 
 extern "C" int tfrec_sort_pairs_u32(tfrec_ctx *ctx, const uint32_t *d_keys_in, const uint32_t *d_vals_in, uint32_t *d_keys_out,

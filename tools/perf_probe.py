@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--apr", type=int, default=0, help="time the APR step at this batch size")
     ap.add_argument("--dns", type=int, default=0, help="time the DNS selection for this many positives (32 candidates each)")
+    ap.add_argument("--versioned", action="store_true", help="steps on a versioned user table (tfrec_utable)")
     ap.add_argument("--plain-only", action="store_true", help="only the un-pipelined steps (for counter collection)")
     a = ap.parse_args()
     torch.cuda.set_device(0)
@@ -44,6 +45,7 @@ def main():
     P = (torch.rand(a.U, a.d, device=cuda, generator=gen) - 0.5) * 0.1
     Q = (torch.rand(a.I, a.d, device=cuda, generator=gen) - 0.5) * 0.1
     b = torch.zeros(a.I, device=cuda)
+    ut = dev.user_table(P) if a.versioned else None
     for B in [int(x) for x in a.batches.split(",") if x]:
         n = B * 4
         users = torch.randint(0, a.U, (n,), device=cuda, generator=gen, dtype=torch.int32)
@@ -52,7 +54,10 @@ def main():
         dev.reserve(B, a.d)
         def step(s):
             o = (s % 4) * B
-            dev.bpr_sgd_step(P, Q, b, users[o:o + B], pos[o:o + B], neg[o:o + B], 0.01, 0.05)
+            if ut is not None:
+                dev.bpr_sgd_step_v(ut, Q, b, users[o:o + B], pos[o:o + B], neg[o:o + B], 0.01, 0.05)
+            else:
+                dev.bpr_sgd_step(P, Q, b, users[o:o + B], pos[o:o + B], neg[o:o + B], 0.01, 0.05)
         for s in range(3):
             step(s)
         torch.cuda.synchronize()
@@ -78,7 +83,10 @@ def main():
                 g, r = divmod(s, K)
                 if r == 0:
                     dev.prepare_batches((g + 1) & 1, a.U, a.I, *grp, K)
-                dev.bpr_sgd_step_prepared(g & 1, P, Q, b, 0.01, 0.05)
+                if ut is not None:
+                    dev.bpr_sgd_step_prepared_v(g & 1, ut, Q, b, 0.01, 0.05)
+                else:
+                    dev.bpr_sgd_step_prepared(g & 1, P, Q, b, 0.01, 0.05)
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / nst
             print(f"B={B}: plain {ms_plain:.3f} ms/step, pipelined K={K} {ms:.3f} ms/step")
@@ -94,6 +102,8 @@ def main():
         uu = torch.unique(users[:B]).numel(); ui = torch.unique(torch.cat([pos[:B], neg[:B]])).numel()
         print(f"B={B:8d} {a.dist}: {ms:8.3f} ms/step  {rate/1e9:6.3f} G triples/s  algorithmic {alg:5.2f} TB/s ({alg/8*100:4.1f}% of 8 TB/s)"
               f"  uniq users {uu} items {ui}  phases " + " ".join(f"{k}={v*1e3:.0f}us" for k, v in acc.items()), flush=True)
+    if ut is not None:
+        ut.close()
     if a.apr:
         B = a.apr
         users = torch.randint(0, a.U, (B,), device=cuda, generator=gen, dtype=torch.int32)
