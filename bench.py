@@ -64,7 +64,7 @@ def pmc_traffic(B, d):
     return t["bytes_per_step"]
 
 
-def other_paths(dev, P, Q, b, U, I, d, B, gen, cuda, steps=10):
+def other_paths(dev, P, Q, b, U, I, d, B, gen, cuda, steps=10, epoch_pipeline=True):
     """APR step (model/APR.py:156-164) and DNS selection (model/DNSBPR.py:68-79) on the same tables:
     throughput and the algorithmic HBM rate; timed outside the K steps of the headline metric."""
     out = {}
@@ -106,6 +106,8 @@ def other_paths(dev, P, Q, b, U, I, d, B, gen, cuda, steps=10):
                          "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                       "algorithmic_bytes_per_positive": per}}
     del cand, sel
+    if not epoch_pipeline:
+        return out
     # device epoch pipeline: draw one negative per stored interaction (rejection against the user's row),
     # shuffle, gather -- the work of model/BPR.py:50-62 + data/dataiterator.py:52-54 for one epoch
     deg = 16
@@ -130,6 +132,51 @@ def other_paths(dev, P, Q, b, U, I, d, B, gen, cuda, steps=10):
     out["device_epoch_pipeline"] = {"triples_per_s": nnz / (ms * 1e-3), "ms_per_epoch": ms, "interactions": nnz,
                                     "note": "sample + shuffle + gather of one epoch; the host sampler of the reference is O(items) per user on one core"}
     return out
+
+
+def large_shape(dev, cuda, U=10_000_000, I=2_000_000, d=128, B=1 << 22, steps=10):
+    """The training paths at the table shape of the largest configuration (10M users x 2M items, d=128; 6.1 GB of
+    tables, far beyond the 256 MiB last-level cache), one GPU: BPR step on a versioned user table, APR step, DNS
+    selection.  Timed outside the K steps of the headline metric."""
+    g = torch.Generator(device=cuda)
+    g.manual_seed(4242)
+    P = (torch.rand(U, d, device=cuda, generator=g) - 0.5) * 0.1
+    Q = (torch.rand(I, d, device=cuda, generator=g) - 0.5) * 0.1
+    b = torch.zeros(I, device=cuda)
+    nb = 4
+    users = torch.randint(0, U, (nb * B,), device=cuda, generator=g, dtype=torch.int32)
+    pos = zipf_items(I, nb * B, g, cuda)
+    neg = torch.randint(0, I, (nb * B,), device=cuda, generator=g, dtype=torch.int32)
+    dev.reserve(B, d)
+    ut = dev.user_table(P)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def grp(s):
+        o = (s % nb) * B
+        return users[o:o + B], pos[o:o + B], neg[o:o + B]
+
+    def bpr(s):
+        # as in the headline loop: the index of batch s+1 is sorted on the auxiliary stream beside the row passes of batch s
+        dev.prepare_batches((s + 1) & 1, U, I, *grp(s + 1), 1)
+        dev.bpr_sgd_step_prepared_v(s & 1, ut, Q, b, 0.01, 0.05)
+    dev.prepare_batches(0, U, I, *grp(0), 1)
+    for s in range(4):
+        bpr(s)
+    e0.record()
+    for s in range(steps):
+        bpr(4 + s)
+    e1.record(); torch.cuda.synchronize()
+    ut.close()
+    ms = e0.elapsed_time(e1) / steps
+    gbs = (24 * d + 28) * B / (ms * 1e-3) / 1e9
+    res = {"shape": "%d users x %d items, d=%d, %d triples per step, one GPU" % (U, I, d, B),
+           "bpr_sgd_step": {"triples_per_s": B / (ms * 1e-3), "ms_per_step": ms, "user_table": "versioned",
+                            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                         "algorithmic_bytes_per_triple": 24 * d + 28}}}
+    del users, pos, neg
+    oth = other_paths(dev, P, Q, b, U, I, d, B, g, cuda, steps=steps, epoch_pipeline=False)
+    res.update(oth)
+    return res
 
 
 def eval_block(dev, cuda, n, I, d, k, deg, tdeg, label):
@@ -283,12 +330,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--no-c5", action="store_true", help="skip the evaluation block at the 2M-item, d=128, k=100 shape")
+    ap.add_argument("--no-large", action="store_true", help="skip the BPR / APR / DNS timings at the 10M-user x 2M-item, d=128 shape")
     ap.add_argument("--no-other", action="store_true", help="skip the APR step and DNS selection timings")
     ap.add_argument("--prep-batches", type=int, default=1, help="batches sorted per index preparation (single GPU)")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU code path even on one GPU (testing)")
     ap.add_argument("--item-mode", default="auto", choices=["auto", "dense", "sharded"],
                     help="multi-GPU item table: replicated with one all-reduce of gradient sums per step, or sharded with all-to-all lookups")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend for N>1 (gloo: testing only)")
+    ap.add_argument("--force-dist", action="store_true", help="testing: with one rank, still create the process group, so that "
+                    "every collective of the multi-GPU path runs (trivially) through the chosen backend")
     ap.add_argument("--single-device", action="store_true", help="testing: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--plain-table", action="store_true", help="single GPU: plain user table (pre-step rows staged per triple) instead of the versioned one")
     ap.add_argument("--no-extras", action="store_true", help="skip the timing of the reference batch size (512 triples per step)")
@@ -307,8 +357,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     cuda = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=cuda)
         else:
@@ -397,7 +451,7 @@ def main():
             return float(t.item())
 
         def barrier():
-            if world > 1:
+            if world > 1 or args.force_dist:
                 torch.distributed.barrier()
             torch.cuda.synchronize()
 
@@ -413,7 +467,7 @@ def main():
         barrier()
         wall = time.perf_counter() - t0
         dev_ms = e0.elapsed_time(e1)
-        if world > 1:
+        if world > 1 or args.force_dist:
             wall = max_over_ranks(wall)
         dev.synchronize()        # raises if any batch held an out-of-range index
 
@@ -472,7 +526,7 @@ def main():
                     se.evaluate()
                     barrier()
                     dt = time.perf_counter() - t1
-                    if world > 1:
+                    if world > 1 or args.force_dist:
                         dt = max_over_ranks(dt)
                     tf = 2.0 * I * d * n / dt / 1e12
                     ev[name] = {"users_per_s": n / dt, "ms": dt * 1e3, "users": n, "items": I, "topk": k, "layout": se.layout + "-sharded",
@@ -495,7 +549,7 @@ def main():
                     apr.step(*batch(3 + s), global_batch=B * world)
                 barrier()
                 dt = time.perf_counter() - t1
-                if world > 1:
+                if world > 1 or args.force_dist:
                     dt = max_over_ranks(dt)
                 apr_bytes = 84 * d + 68
                 per_gpu = B * apr_bytes / (dt / apr_steps) / 1e9
@@ -570,13 +624,15 @@ def main():
                 out["eval"] = ev
             if not args.no_other:
                 out["other_paths"] = other_paths(dev, P, Q, b, U, I, d, B, gen, cuda)
+                if not args.no_large:
+                    guarded("large_shape", lambda: large_shape(dev, cuda))
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(U, I, d, 1 << 17, lr, reg)
                 if "eval" in out and "error" not in out["eval"]:
                     out["eval"]["cpu_baseline"] = cpu_baseline_eval(I, d, args.topk)
         if rank == 0:
             print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_dist:
         torch.distributed.destroy_process_group()
 
 

@@ -232,6 +232,9 @@ class ShardedBprTrainer:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # collectives run whenever a process group exists, also one of a single rank (where they are trivial): the
+        # single-rank run then takes the same path as the many-rank one
+        self._coll = dist.is_initialized()
         self.U, self.I, self.d, self.lr, self.reg = int(U), int(I), int(d), float(lr), float(reg)
         self.upr, self.ipr = _part(self.U, self.world), _part(self.I, self.world)
         self.user_range = (min(self.rank * self.upr, self.U), min((self.rank + 1) * self.upr, self.U))
@@ -285,7 +288,7 @@ class ShardedBprTrainer:
     def _a2a(self, send, send_counts, recv_counts):
         """all_to_all_single with per-rank row counts (lists of ints)."""
         out = torch.empty((int(sum(recv_counts)),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
-        if self.world == 1:
+        if not self._coll:
             out.copy_(send)
             return out
         _all_to_all_rows(out, send, recv_counts, send_counts, self.group)
@@ -322,7 +325,7 @@ class ShardedBprTrainer:
             self._pending.pop(slot, None)        # consumed: the step that read the slot is enqueued
         if prepare_next is not None:
             self.prepare(*prepare_next)
-        if self.world > 1:
+        if self._coll:
             _all_reduce(self._G, self.group)
         self.backend.axpy(self._Qb, self._G, -self.lr)
 
@@ -350,7 +353,7 @@ class ShardedBprTrainer:
             pos, neg = pos.to(torch.int32).contiguous(), neg.to(torch.int32).contiguous()
             uniq, ps, ns = self.backend.items_dedup(pos, neg, self.I, self.ipr, W, counts[s])
             plans.append({"B": int(users.shape[0]), "users": users, "pos_slot": ps, "neg_slot": ns, "uniq": uniq})
-        if W > 1:
+        if self._coll:
             asked = torch.empty((W, S), dtype=torch.int64, device=dev)          # row r: what rank r asks of me, per step
             _all_to_all_rows(asked, counts.t().contiguous(), [1] * W, [1] * W, self.group)
         else:
@@ -388,7 +391,7 @@ class ShardedBprTrainer:
         shards (collective).  Read-only use, e.g. the epoch-start candidate scoring of DNS."""
         if self.item_mode == "dense":
             return self.Q_full, self.b_full
-        if self.world == 1:
+        if not self._coll:
             return self.Q, self.b
 
         def cat(x):
@@ -401,7 +404,7 @@ class ShardedBprTrainer:
     def gather_full(self):
         """(P, Q, b) assembled on every rank (testing / checkpointing)."""
         def cat(x, n):
-            if self.world == 1:
+            if not self._coll:
                 return x.clone()
             per = _part(n, self.world)
             pad = torch.zeros((per,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
@@ -433,6 +436,9 @@ class ShardedAprTrainer:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # collectives run whenever a process group exists, also one of a single rank (where they are trivial): the
+        # single-rank run then takes the same path as the many-rank one
+        self._coll = dist.is_initialized()
         self.U, self.I, self.d = int(U), int(I), int(d)
         self.lr, self.reg, self.reg_adv, self.eps = float(lr), float(reg), float(reg_adv), float(eps)
         self.upr, self.ipr = _part(self.U, self.world), _part(self.I, self.world)
@@ -467,7 +473,7 @@ class ShardedAprTrainer:
         self.b = self.b_full[self.item_range[0]:self.item_range[1]]
 
     def _sum_over_ranks(self, t):
-        if self.world > 1:
+        if self._coll:
             _all_reduce(t, self.group)
 
     def step(self, users, pos, neg, global_batch=None, loss=None):
@@ -500,7 +506,7 @@ class ShardedAprTrainer:
 
     def gather_full(self):
         """(P, Q, b) assembled on every rank (testing / checkpointing)."""
-        if self.world == 1:
+        if not self._coll:
             return self.P.clone(), self.Q_full.clone(), self.b_full.clone()
         pad = torch.zeros((self.upr, self.d), dtype=self.P.dtype, device=self.device)
         pad[: self.P.shape[0]] = self.P
@@ -533,7 +539,7 @@ class ShardedEvaluator:
     def _gather_lists(self, x):
         """[n, k] per rank -> [world, n, k] on every rank (800 bytes per user and rank at k=100)."""
         t = self.t
-        if t.world == 1:
+        if not t._coll:
             return x.unsqueeze(0)
         return torch.stack(_all_gather(x, t.world, t.group))
 
@@ -549,7 +555,7 @@ class ShardedEvaluator:
             if self.train is not None:
                 self.backend.fill_masked(ids, eu, k, self.train)
             sums += self.backend.metric_sums(ids, eu, k, self.test)
-        if t.world > 1:
+        if t._coll:
             _all_reduce(sums, t.group)
         return (sums / float(self.test_users.shape[0])).to(torch.float32).reshape(5, k)
 
@@ -570,7 +576,7 @@ class ShardedEvaluator:
                     rows = t.P.index_select(0, eu.to(torch.int64) - t.user_range[0]).contiguous()
                 else:
                     rows = torch.empty((n, t.d), dtype=torch.float32, device=dev)
-                if W > 1:
+                if t._coll:
                     _broadcast(rows, o, t.group)
                 ids, sc = self.backend.score_topk_shard(rows, t.Q, t.b, t.item_range[0], eu, k, self.train, self.mode)
                 all_ids, all_sc = self._gather_lists(ids), self._gather_lists(sc)
@@ -579,7 +585,7 @@ class ShardedEvaluator:
                     if self.train is not None:
                         self.backend.fill_masked(mi, eu, k, self.train)
                     sums += self.backend.metric_sums(mi, eu, k, self.test)
-        if W > 1:
+        if t._coll:
             _all_reduce(sums, t.group)
         return (sums / float(self.test_users.shape[0])).to(torch.float32).reshape(5, k)
 
@@ -637,7 +643,7 @@ class ShardedEpochSampler:
         t = self.t
         users, pos, neg = self.epoch(e)
         steps = torch.tensor([(self.nnz + batch_size - 1) // batch_size], dtype=torch.int64, device=t.device)
-        if t.world > 1:
+        if t._coll:
             _all_reduce(steps, t.group, op=dist.ReduceOp.MAX)
         n_steps = int(steps.item())
         batches = []
