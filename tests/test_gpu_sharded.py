@@ -150,7 +150,8 @@ def test_sharded_epoch_sampler_on_the_gpu(oracle, item_mode):
     for u in range(U):
         c = rng.permutation(I)[: int(rng.integers(0, 12))]
         rows += [u] * len(c); cols += c.tolist()
-    m = sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(U, I)); m.sort_indices()
+    from tfrec_amd.utils.tools import csr_trained_rows
+    m = csr_trained_rows(sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(U, I)))
     tr = ShardedBprTrainer(dev, U, I, d, 0.05, 0.01, seed=3, item_mode=item_mode)
     P, Q, b = [x.cpu().numpy().copy() for x in tr.gather_full()]
     s = ShardedEpochSampler(dev, tr, m, seed=17, n_neg=C)
@@ -291,8 +292,8 @@ def _c4_matrix():
     for u in range(C4["U"]):
         c = rng.permutation(C4["I"])[: int(rng.integers(1, 14))]
         rows += [u] * len(c); cols += c.tolist()
-    m = sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(C4["U"], C4["I"])); m.sort_indices()
-    return m
+    from tfrec_amd.utils.tools import csr_trained_rows
+    return csr_trained_rows(sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(C4["U"], C4["I"])))
 
 
 def _c4_eval_inputs(cuda):

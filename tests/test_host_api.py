@@ -63,6 +63,27 @@ def test_csr_to_user_dict_quirk(golden_sampler):
         csr_to_user_dict(np.zeros((2, 2)))
 
 
+def test_csr_trained_rows_keeps_exactly_the_users_of_csr_to_user_dict(golden_sampler):
+    """The CSR the device samplers draw from holds the rows csr_to_user_dict keeps, and only those."""
+    from tfrec_amd.utils.tools import csr_trained_rows
+    quirk = sp.csr_matrix((np.ones(4), ([1, 2, 2, 3], [0, 0, 3, 2])), shape=(4, 5))
+    t = csr_trained_rows(quirk)
+    assert np.flatnonzero(np.diff(t.indptr)).tolist() == golden_sampler["quirk_kept_rows"].tolist()
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        U, I = 30, 6
+        rows, cols = [], []
+        for u in range(U):
+            c = rng.permutation(I)[: int(rng.integers(0, 3))]
+            rows += [u] * len(c); cols += c.tolist()
+        m = sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(U, I)); m.sort_indices()
+        t, kept = csr_trained_rows(m), csr_to_user_dict(m)
+        for u in range(U):
+            got = t.indices[t.indptr[u]:t.indptr[u + 1]]
+            assert np.array_equal(got, kept[u]) if u in kept else got.size == 0
+    assert csr_trained_rows(sp.csr_matrix((3, 4))).nnz == 0
+
+
 def test_typeassert_and_argmax_top_k():
     @typeassert(a=int, b=str)
     def f(a, b="x", c=None):
@@ -93,12 +114,19 @@ def test_param_files(tmp_path):
         for trusted in (False, True):
             got = load_params(path, trusted=trusted)
             assert all(np.array_equal(x, y) for x, y in zip(got, (P, Q, b)))
-    # protocol-2 pickles keep array bytes as strings: read without unpickling as well
+    # every pickle protocol numpy arrays are written with (2: array bytes as latin-1 text through _codecs.encode;
+    # 3, 4: bytes in the state tuple; 5: a bytearray handed to _frombuffer), read without unpickling; shapes that
+    # share an element count (U == I, I == U * d) must not be confused, float64 files are narrowed
     path = str(tmp_path / "old.pkl")
-    with open(path, "wb") as f:
-        pickle.dump([P, Q, b], f, protocol=2)
-    got = read_param_pickle_safely(path)
-    assert all(np.array_equal(x, y) for x, y in zip(got, (P, Q, b)))
+    for U, I, d in ((7, 5, 4), (5, 5, 4), (3, 12, 4), (1, 1, 1), (300, 200, 16)):
+        for dt in (np.float32, np.float64):
+            P2, Q2, b2 = rng.normal(size=(U, d)).astype(dt), rng.normal(size=(I, d)).astype(dt), rng.normal(size=I).astype(dt)
+            for proto in (2, 3, 4, 5):
+                with open(path, "wb") as f:
+                    pickle.dump([P2, Q2, b2], f, protocol=proto)
+                got = read_param_pickle_safely(path)
+                for x, y in zip(got, (P2, Q2, b2)):
+                    assert x.dtype == np.float32 and x.shape == y.shape and np.array_equal(x, y.astype(np.float32)), (U, I, d, dt, proto)
     bad = str(tmp_path / "bad.pkl")
     with open(bad, "wb") as f:
         pickle.dump([os.path.join, 1], f)

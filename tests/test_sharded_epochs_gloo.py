@@ -21,9 +21,10 @@ U, I, D, BATCH, NEG = 61, 47, 8, 40, 5
 def _matrix():
     rng = np.random.default_rng(21)
     rows, cols = [], []
-    for u in range(U):
+    for u in range(U - 1):
         c = rng.permutation(I)[: int(rng.integers(0, 9))]
         rows += [u] * len(c); cols += c.tolist()
+    rows.append(U - 1); cols.append(0)        # the last user's only item is item 0: the reference does not train it (utils/tools.py:52-62)
     m = sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(U, I)); m.sort_indices()
     return m
 
@@ -79,7 +80,10 @@ def runs(tmp_path_factory):
 
 
 def test_shard_draws_equal_the_whole_matrix_draws(runs, oracle):
-    m = _matrix()
+    sys.path.insert(0, ROOT)
+    from tfrec_amd.utils.tools import csr_trained_rows
+    m = csr_trained_rows(_matrix())
+    assert m.nnz == _matrix().nnz - 1
     P = np.random.default_rng(11).uniform(-0.05, 0.05, (U, D)).astype(np.float32)
     Q = np.random.default_rng(12).uniform(-0.05, 0.05, (I, D)).astype(np.float32)
     b = np.zeros(I, np.float32)

@@ -43,10 +43,19 @@ struct Acc {
 #define TF_TILE_CH 64
 #endif
 constexpr int tile_ch(int lpr) { return lpr > TF_TILE_CH ? lpr : TF_TILE_CH; }
+// Short tiles for small batches: a lane group walks its tile in order, so the tile length is the step's
+// latency when there are too few tiles to fill the chip anyway (a policy opts in with `enum { SHORT_TILES = 1 }`).
+constexpr int short_tile_ch(int lpr) { return lpr > 16 ? lpr : 16; }
+template <class Pol>
+constexpr int pol_ch()
+{
+    if constexpr (requires { Pol::SHORT_TILES; }) return Pol::SHORT_TILES ? short_tile_ch(Pol::LPR) : tile_ch(Pol::LPR);
+    else return tile_ch(Pol::LPR);
+}
 
-template <int LPR>
+template <int LPR, int CH_>
 struct TileGeom {
-    static constexpr int CH = tile_ch(LPR);          // occurrences per tile
+    static constexpr int CH = CH_;                   // occurrences per tile
     static constexpr int EPL = CH / LPR;             // entries staged per lane
     static constexpr int GPB = 256 / LPR;            // groups (= tiles) per 256-thread workgroup
 };
@@ -112,7 +121,7 @@ __global__ __launch_bounds__(256) void seg_tile_kernel(Pol pol, const uint32_t *
 {
     constexpr int LPR = Pol::LPR, NCH = Pol::NCH, VEC = Pol::VEC;
     using RowT = typename Pol::RowT;
-    using G = TileGeom<LPR>;
+    using G = TileGeom<LPR, pol_ch<Pol>()>;
     constexpr int CH = G::CH, EPL = G::EPL, GPB = G::GPB;
     constexpr int ROWF = LPR * NCH * VEC;
     __shared__ uint4 ent[GPB][CH];
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(256) void seg_fixup_kernel(Pol pol, const uint32_t 
 {
     constexpr int LPR = Pol::LPR, NCH = Pol::NCH, VEC = Pol::VEC;
     using RowT = typename Pol::RowT;
-    using G = TileGeom<LPR>;
+    using G = TileGeom<LPR, pol_ch<Pol>()>;
     constexpr int CH = G::CH, GPB = G::GPB;
     constexpr int ROWF = LPR * NCH * VEC;
     __shared__ int64_t long_w[GPB];

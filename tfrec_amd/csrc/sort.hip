@@ -240,39 +240,101 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(Src src,
 
 // Small batches (the reference's 512 or 128 triples a step): the radix passes above are nine launches that finish
 // in microseconds each, so a step is bound by its launches.  Up to SMALL_MAX pairs are sorted by ONE workgroup
-// instead: (key, value) words in LDS, bitonic network.  Ordering by the 64-bit word equals the stable order by key
+// instead: a bitonic network over 64-bit (key, value) words.  Ordering by the word equals the stable order by key
 // because the values of a training batch ascend in input order (occurrence ids).
+// A thread keeps E consecutive words in registers.  A stage whose partner distance stays inside the thread is
+// register work, one whose partner is in the same wave is a lane exchange, and only the stages that cross waves
+// (6 to 10 of the up to 91) go through LDS and its barriers.
 constexpr int SMALL_MAX = 8192;
 
-template <class Src>
-__global__ __launch_bounds__(1024) void sort_small_kernel(Src src, uint32_t n, uint32_t npad, uint32_t *__restrict__ kout,
-                                                          uint32_t *__restrict__ vout)
+template <class Src, int E, int NT>
+__global__ __launch_bounds__(NT) void sort_small_kernel(Src src, uint32_t n, uint32_t *__restrict__ kout, uint32_t *__restrict__ vout)
 {
-    __shared__ uint64_t e[SMALL_MAX];
+    constexpr uint32_t NP = (uint32_t)E * NT;
+    __shared__ uint64_t e[NP];
     bool bad = false;
-    for (uint32_t i = threadIdx.x; i < npad; i += 1024) {
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const uint32_t i = (uint32_t)r * NT + threadIdx.x;
         uint32_t k = 0, v = 0;
         src.load(i < n ? i : n - 1, k, v, bad);
         e[i] = i < n ? ((uint64_t)k << 32) | v : ~0ull;
     }
     src.report(bad);
     __syncthreads();
-    for (uint32_t k2 = 2; k2 <= npad; k2 <<= 1) {
+    const uint32_t i0 = threadIdx.x * E;
+    uint64_t x[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) x[r] = e[i0 + r];
+    __syncthreads();
+
+    // word i keeps the smaller of (its own, its partner's) when it is the lower index of an ascending pair or the
+    // upper index of a descending one
+    auto keep = [&](uint64_t mine, uint64_t other, uint32_t i, uint32_t j, uint32_t k2) {
+        const bool take_min = ((i & j) == 0) == ((i & k2) == 0);
+        const bool other_less = other < mine;
+        return (other_less == take_min) ? other : mine;
+    };
+    for (uint32_t k2 = 2; k2 <= NP; k2 <<= 1) {
         for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = threadIdx.x; t < npad / 2; t += 1024) {
-                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
-                const uint64_t a = e[i], b = e[p];
-                const bool up = (i & k2) == 0;
-                if ((a > b) == up) { e[i] = b; e[p] = a; }
+            if (j < (uint32_t)E) {
+                // partner inside the thread (j is 1, 2 or 4: spelled out so that x[] stays in registers)
+#pragma unroll
+                for (int J = 1; J < E; J <<= 1) {
+                    if (j == (uint32_t)J) {
+#pragma unroll
+                        for (int r = 0; r < E; ++r) {
+                            if ((r & J) == 0) {
+                                const uint64_t a = x[r], b = x[r | J];
+                                const bool up = ((i0 + r) & k2) == 0;
+                                const bool sw = (a > b) == up;
+                                x[r] = sw ? b : a;
+                                x[r | J] = sw ? a : b;
+                            }
+                        }
+                    }
+                }
+            } else if (j < 64u * E) {
+                const int m = (int)(j / E);                   // partner lane = lane ^ m, same register
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x[r], m, 64);
+                    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(x[r] >> 32), m, 64);
+                    x[r] = keep(x[r], ((uint64_t)hi << 32) | lo, i0 + r, j, k2);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < E; ++r) e[i0 + r] = x[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < E; ++r) x[r] = keep(x[r], e[(i0 + r) ^ j], i0 + r, j, k2);
+                __syncthreads();
             }
-            __syncthreads();
         }
     }
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
-        const uint64_t w = e[i];
-        kout[i] = (uint32_t)(w >> 32);
-        vout[i] = (uint32_t)w;
+#pragma unroll
+    for (int r = 0; r < E; ++r) e[i0 + r] = x[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const uint32_t i = (uint32_t)r * NT + threadIdx.x;
+        if (i < n) {
+            const uint64_t w = e[i];
+            kout[i] = (uint32_t)(w >> 32);
+            vout[i] = (uint32_t)w;
+        }
     }
+}
+
+template <class Src>
+static void sort_small_launch(const Src &src, uint32_t n, uint32_t *kout, uint32_t *vout, hipStream_t stream)
+{
+    if (n <= 256) sort_small_kernel<Src, 1, 256><<<1, 256, 0, stream>>>(src, n, kout, vout);
+    else if (n <= 512) sort_small_kernel<Src, 2, 256><<<1, 256, 0, stream>>>(src, n, kout, vout);
+    else if (n <= 1024) sort_small_kernel<Src, 2, 512><<<1, 512, 0, stream>>>(src, n, kout, vout);
+    else if (n <= 2048) sort_small_kernel<Src, 4, 512><<<1, 512, 0, stream>>>(src, n, kout, vout);
+    else if (n <= 4096) sort_small_kernel<Src, 4, 1024><<<1, 1024, 0, stream>>>(src, n, kout, vout);
+    else sort_small_kernel<Src, 8, 1024><<<1, 1024, 0, stream>>>(src, n, kout, vout);
 }
 
 constexpr int SORT_RB_MAX = TF_SORT_RB_MAX;      // widest digit
@@ -346,10 +408,8 @@ int sort_run(void *d_temp, size_t temp_bytes, const tfrec_triple_src *first_src,
     TF_REQUIRE(n < (1ull << 32), TFREC_EUNSUP, "sort of %zu pairs: positions must fit 32 bits", n);
     TF_REQUIRE(end_bit >= 1 && end_bit <= 32, TFREC_EINVAL, "sort key width %d out of range", end_bit);
     if (first_src && n <= (size_t)SMALL_MAX) {
-        uint32_t npad = 2;
-        while (npad < n) npad <<= 1;
-        if (first_src->inv_B) sort_small_kernel<TripleSrcT<true>><<<1, 1024, 0, stream>>>(TripleSrcT<true>{*first_src}, (uint32_t)n, npad, keys_out, vals_out);
-        else sort_small_kernel<TripleSrcT<false>><<<1, 1024, 0, stream>>>(TripleSrcT<false>{*first_src}, (uint32_t)n, npad, keys_out, vals_out);
+        if (first_src->inv_B) sort_small_launch(TripleSrcT<true>{*first_src}, (uint32_t)n, keys_out, vals_out, stream);
+        else sort_small_launch(TripleSrcT<false>{*first_src}, (uint32_t)n, keys_out, vals_out, stream);
         TF_HIP(hipGetLastError());
         return TFREC_OK;
     }

@@ -42,6 +42,9 @@ __device__ __forceinline__ uint32_t clamp_index(int32_t v, uint32_t n, bool *bad
 #ifndef TF_DEPTH_ITEM
 #define TF_DEPTH_ITEM 4
 #endif
+#ifndef TF_SHORT_TILES_MAX_B
+#define TF_SHORT_TILES_MAX_B 131072
+#endif
 
 struct BprParams {
     float *P, *Q, *b;
@@ -63,9 +66,9 @@ struct BprParams {
 };
 
 // VER: the user table is versioned (see BprParams): no pre-step rows are staged for the item pass.
-template <int LPR_, int NCH_, int VEC_, bool FULL_, bool LOSS, bool VER = false>
+template <int LPR_, int NCH_, int VEC_, bool FULL_, bool LOSS, bool VER = false, bool SHORT = false>
 struct BprUserPol {
-    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_, DEPTH = TF_DEPTH_USER };
+    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_, DEPTH = TF_DEPTH_USER, SHORT_TILES = SHORT };
     using RowT = Row<LPR_, NCH_, VEC_>;
     using DM = RowDims<LPR_, NCH_, VEC_, FULL_>;
     using Loss = LossAcc<LOSS ? 2 : 0>;
@@ -135,9 +138,9 @@ struct BprUserPol {
 // distinct item in row `it` of gQ / entry `it` of gb instead.  Those are either Q, b themselves
 // (the tables then hold fetched copies of rows owned by other GPUs, and the sums travel back to
 // the owners) or a zeroed table of the shape of Q, b that is then summed over the GPUs.
-template <int LPR_, int NCH_, int VEC_, bool FULL_, bool GRAD = false, bool VER = false>
+template <int LPR_, int NCH_, int VEC_, bool FULL_, bool GRAD = false, bool VER = false, bool SHORT = false>
 struct BprItemPol {
-    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_, DEPTH = TF_DEPTH_ITEM };
+    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_, DEPTH = TF_DEPTH_ITEM, SHORT_TILES = SHORT };
     using RowT = Row<LPR_, NCH_, VEC_>;
     using DM = RowDims<LPR_, NCH_, VEC_, FULL_>;
     using Loss = LossAcc<0>;
@@ -666,9 +669,13 @@ struct StepWs {
     int blocks_u, blocks_i;
 };
 
+// batches up to this many triples run the BPR row passes on short tiles
+static constexpr int64_t SHORT_TILES_MAX_B = TF_SHORT_TILES_MAX_B;
+
+// (sized for the short tiles of small batches where those may be used: more tiles, more partial records)
 static size_t step_ws_bytes(int64_t B, int d, const RowCfg &c)
 {
-    const int CH = tile_ch(c.lpr);
+    const int CH = B <= SHORT_TILES_MAX_B ? short_tile_ch(c.lpr) : tile_ch(c.lpr);
     const int64_t tiles = (2 * B + CH - 1) / CH + 1;      // the larger (item) side
     const size_t rowf = (size_t)c.lpr * c.nch * c.vec;
     size_t s = 0;
@@ -698,10 +705,10 @@ size_t tfrec_step_need_bytes(int64_t B, int d)
     return best;
 }
 
-static int step_ws_carve(tfrec_ctx *ctx, int64_t B, int d, const RowCfg &c, StepWs *w, bool with_stage = true)
+static int step_ws_carve(tfrec_ctx *ctx, int64_t B, int d, const RowCfg &c, StepWs *w, bool with_stage = true, bool short_tiles = false)
 {
     TF_TRY(tfrec_ws_require(ctx, ctx->ws_used + step_ws_bytes(B, d, c)));
-    const int CH = tile_ch(c.lpr), GPB = 256 / c.lpr;
+    const int CH = short_tiles ? short_tile_ch(c.lpr) : tile_ch(c.lpr), GPB = 256 / c.lpr;
     const int64_t tiles = (2 * B + CH - 1) / CH + 1;
     const size_t rowf = (size_t)c.lpr * c.nch * c.vec;
     w->stage = with_stage ? (float *)tfrec_ws_take(ctx, sizeof(float) * (size_t)B * d) : nullptr;
@@ -800,28 +807,37 @@ static int bpr_passes(tfrec_ctx *ctx, const tfrec_batch_slot &sl, float *d_P, fl
     RowCfg cfg;
     TF_REQUIRE(pick_cfg(d, all_aligned16({d_P, d_Q, ut ? ut->P2 : nullptr}), &cfg), TFREC_EUNSUP, "factor size d=%d is not supported (max 256)", d);
     StepWs w;
-    TF_TRY(step_ws_carve(ctx, B, d, cfg, &w, ut == nullptr));
+    const bool short_tiles = B <= SHORT_TILES_MAX_B;
+    TF_TRY(step_ws_carve(ctx, B, d, cfg, &w, ut == nullptr, short_tiles));
     BprParams a{d_P, d_Q, d_b, ut ? ut->P2 : nullptr, ut ? ut->ver : nullptr, d_gQ ? d_gQ : d_Q, d_gb ? d_gb : d_b, w.stage, w.sbuf,
                 sl.pair + B * k0, sl.users_raw + B * k0, (uint32_t)U, d, d / cfg.vec, lr, reg, sl.kmask};
     const bool want_loss = d_loss != nullptr;
-    auto passes = [&]<int LPR, int NCH, int VEC, bool FULL, bool VER>() -> int {
+    auto passes = [&]<int LPR, int NCH, int VEC, bool FULL, bool VER, bool SHORT>() -> int {
         if (want_loss) {
-            TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, FULL, true, VER>{a}, w, keys, vals, 0, B, w.n_tiles_u, w.blocks_u, true,
+            TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, FULL, true, VER, SHORT>{a}, w, keys, vals, 0, B, w.n_tiles_u, w.blocks_u, true,
                             "user_tile", "user_fixup"));
             loss_finalize_kernel<2><<<1, 256, 0, ctx->stream>>>(w.loss_part, w.blocks_u, d_loss);
             TF_HIP(hipGetLastError());
         } else {
-            TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, FULL, false, VER>{a}, w, keys, vals, 0, B, w.n_tiles_u, w.blocks_u, false,
+            TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, FULL, false, VER, SHORT>{a}, w, keys, vals, 0, B, w.n_tiles_u, w.blocks_u, false,
                             "user_tile", "user_fixup"));
         }
         if (item_grad_only)
-            return run_pass(ctx, BprItemPol<LPR, NCH, VEC, FULL, true, VER>{a}, w, keys, vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false,
+            return run_pass(ctx, BprItemPol<LPR, NCH, VEC, FULL, true, VER, SHORT>{a}, w, keys, vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false,
                             "item_tile", "item_fixup");
-        return run_pass(ctx, BprItemPol<LPR, NCH, VEC, FULL, false, VER>{a}, w, keys, vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false,
+        return run_pass(ctx, BprItemPol<LPR, NCH, VEC, FULL, false, VER, SHORT>{a}, w, keys, vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false,
                         "item_tile", "item_fixup");
     };
-    if (!ut) return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC, bool FULL>() -> int { return passes.template operator()<LPR, NCH, VEC, FULL, false>(); });
-    TF_TRY(dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC, bool FULL>() -> int { return passes.template operator()<LPR, NCH, VEC, FULL, true>(); }));
+    auto layout = [&]<bool VER>() -> int {
+        return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC, bool FULL>() -> int {
+            // (a lane group of 64 has no shorter tile than the regular one)
+            if constexpr (short_tile_ch(LPR) < tile_ch(LPR))
+                if (short_tiles) return passes.template operator()<LPR, NCH, VEC, FULL, VER, true>();
+            return passes.template operator()<LPR, NCH, VEC, FULL, VER, false>();
+        });
+    };
+    if (!ut) return layout.template operator()<false>();
+    TF_TRY(layout.template operator()<true>());
     utable_flip_kernel<<<(unsigned)((B + 255) / 256), 256, 0, ctx->stream>>>(keys, B, sl.kmask, ut->ver);
     TF_HIP(hipGetLastError());
     tfrec_mark(ctx, "version_flip");

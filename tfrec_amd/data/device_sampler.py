@@ -5,14 +5,19 @@ Same distribution and exclusion rule as the reference -- per stored interaction 
 ``n_neg``) drawn uniformly, with replacement, from the items the user has not interacted with; then
 a shuffle -- but the random numbers are the library's counter-based draws, not numpy's global
 stream, which cannot be drawn in parallel.  Epoch ``e`` of a sampler is a pure function of
-``(seed, e)`` and of the training matrix."""
+``(seed, e)`` and of the training matrix.
+
+Who is trained is the reference's rule: the users ``csr_to_user_dict`` keeps (utils/tools.py:52-62 drops a user
+whose only item is item 0).  A user who holds every item has no negative to draw: the library reports it through
+its sticky error flag, so the next ``synchronize`` raises instead of training on a positive."""
 import numpy as np
+
+from ..utils.tools import csr_trained_rows
 
 
 class DeviceEpochSampler:
     def __init__(self, dev, train_matrix, seed=2018, n_neg=1, first_interaction=0):
-        csr = train_matrix.tocsr()
-        csr.sort_indices()
+        csr = csr_trained_rows(train_matrix)
         self.dev = dev
         self.n_users, self.n_items = csr.shape
         self.nnz = int(csr.nnz)

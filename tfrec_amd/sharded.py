@@ -601,8 +601,8 @@ class ShardedEpochSampler:
     def __init__(self, dev_or_backend, trainer, train_matrix, seed=2018, n_neg=1):
         self.backend = dev_or_backend if hasattr(dev_or_backend, "uniform_rows") else HipBackend(dev_or_backend)
         self.t = trainer
-        csr = train_matrix.tocsr()
-        csr.sort_indices()
+        from .utils.tools import csr_trained_rows
+        csr = csr_trained_rows(train_matrix)       # the users the reference trains (utils/tools.py:52-62)
         lo, hi = trainer.user_range
         self.first = int(csr.indptr[lo])
         sub = csr[lo:hi]

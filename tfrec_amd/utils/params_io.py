@@ -25,43 +25,58 @@ def read_param_pickle_safely(path):
     """Three float32 arrays from a pickle of [ndarray, ndarray, ndarray] without executing it."""
     with open(path, "rb") as fin:
         raw = fin.read()
-    ints, shapes, blobs, dtypes = [], [], [], []
-    # An ndarray's state tuple is (version, shape, dtype, is_fortran, DATA): the payload is the
-    # bytes/str argument that follows the is_fortran flag (possibly after a memo fetch of
-    # _codecs.encode, which python-3 protocol-2 pickles wrap around a latin-1 text).
-    expect_data = False
+    run, shape, blobs, dtypes = [], None, [], []
+    # An ndarray's state tuple is (version, shape, dtype, is_fortran, DATA).  The payload is the bytes/str argument
+    # that follows the is_fortran flag, possibly after _codecs.encode (named by a GLOBAL the first time, fetched from
+    # the memo afterwards), which python-3 protocol-2 pickles wrap around a latin-1 text.  Its shape is the last
+    # tuple of plain integers before it: the state tuple's second member (what lies between the two -- the dtype
+    # and the flag -- holds no such tuple).  Protocol 5 writes numpy._core.numeric._frombuffer(bytearray, dtype,
+    # shape, order) instead: there the payload comes first and the next tuple of plain integers is its shape.
+    expect_data = await_shape = False
     payload_ops = ("BINBYTES", "SHORT_BINBYTES", "BINBYTES8", "BINSTRING", "SHORT_BINSTRING", "BINUNICODE", "SHORT_BINUNICODE",
                    "BINUNICODE8")
+    int_ops = ("BININT", "BININT1", "BININT2", "LONG1", "INT")
     for op, arg, _ in pickletools.genops(raw):
         name = op.name
+        if name in ("GLOBAL", "STACK_GLOBAL") and arg and not (str(arg).startswith("numpy") or str(arg) == "_codecs encode"):
+            raise ValueError("%s references %r: not a plain numpy parameter pickle" % (path, arg))
         if expect_data and name in payload_ops:
-            blobs.append(arg.encode("latin-1") if isinstance(arg, str) else bytes(arg))
+            blobs.append((arg.encode("latin-1") if isinstance(arg, str) else bytes(arg), shape))
             expect_data = False
+            continue
+        if name == "BYTEARRAY8":
+            blobs.append((bytes(arg), None))
+            await_shape, run = True, []
             continue
         if name in ("NEWFALSE", "NEWTRUE"):
             expect_data = True
+            run = []
             continue
-        if not (expect_data and name in ("BINGET", "LONG_BINGET", "MEMOIZE", "BINPUT", "LONG_BINPUT")):
+        if not (expect_data and (name in ("BINGET", "LONG_BINGET", "MEMOIZE", "BINPUT", "LONG_BINPUT")
+                                 or (name == "GLOBAL" and str(arg) == "_codecs encode"))):
             expect_data = False
-        if name in ("BININT", "BININT1", "BININT2", "LONG1", "INT"):
-            ints.append(int(arg))
-        elif name in ("TUPLE1", "TUPLE2", "TUPLE3"):
+        if name in int_ops:
+            run.append(int(arg))
+            continue
+        if name in ("TUPLE1", "TUPLE2", "TUPLE3"):
             n = int(name[-1])
-            shapes.append(tuple(ints[-n:]) if len(ints) >= n else ())
+            if len(run) >= n:
+                shape = tuple(run[-n:])
+                if await_shape:
+                    blobs[-1], await_shape = (blobs[-1][0], shape), False
         elif name in ("BINUNICODE", "SHORT_BINUNICODE") and arg in ("f4", "f8"):
             dtypes.append(arg)
-        elif name in ("GLOBAL", "STACK_GLOBAL") and arg and not (str(arg).startswith("numpy") or str(arg) == "_codecs encode"):
-            raise ValueError("%s references %r: not a plain numpy parameter pickle" % (path, arg))
+        elif name == "SHORT_BINUNICODE" and arg == "F" and blobs and not await_shape:
+            raise ValueError("%s: column-major arrays are not supported" % path)
+        run = []
     if len(blobs) != 3:
         raise ValueError("%s: expected three array payloads, found %d" % (path, len(blobs)))
     item = 4 if (not dtypes or dtypes[0] == "f4") else 8
     out = []
-    for blob in blobs:
-        n = len(blob) // item
-        match = [s for s in shapes if s and int(np.prod(s)) == n and 0 not in s]
-        if not match:
-            raise ValueError("%s: no shape matches a payload of %d elements" % (path, n))
-        out.append(np.frombuffer(blob, "<f%d" % item).reshape(match[0]).astype(np.float32))
+    for blob, shp in blobs:
+        if not shp or 0 in shp or int(np.prod(shp)) * item != len(blob):
+            raise ValueError("%s: a payload of %d bytes does not fill its shape %r" % (path, len(blob), shp))
+        out.append(np.frombuffer(blob, "<f%d" % item).reshape(shp).astype(np.float32))
     return out
 
 

@@ -65,6 +65,23 @@ def csr_to_user_dict(sparse_matrix_data):
     return out
 
 
+def csr_trained_rows(sparse_matrix_data):
+    """The matrix with the rows ``csr_to_user_dict`` drops emptied (a row whose only item is item 0), sorted
+    indices: what a sampler that works on the CSR arrays themselves must see to train the same users as the
+    reference's dictionary-based one (utils/tools.py:52-62, model/BPR.py:50-62)."""
+    csr = sparse_matrix_data.tocsr().copy()
+    csr.sort_indices()
+    counts = np.diff(csr.indptr)
+    first = csr.indices[np.minimum(csr.indptr[:-1], max(csr.nnz - 1, 0))] if csr.nnz else np.zeros(0, csr.indices.dtype)
+    drop = (counts == 1) & (first == 0) if csr.nnz else np.zeros(csr.shape[0], bool)
+    if drop.any():
+        keep = np.ones(csr.nnz, bool)
+        keep[csr.indptr[:-1][drop]] = False
+        new_counts = np.where(drop, 0, counts)
+        csr = csr_matrix((csr.data[keep], csr.indices[keep], np.concatenate([[0], np.cumsum(new_counts)])), shape=csr.shape)
+    return csr
+
+
 @typeassert(sparse_matrix_data=csr_matrix)
 def csr_to_user_item_pair(sparse_matrix_data):
     """Parallel lists of (user, item) over the non-zeros (utils/tools.py:65-72)."""
