@@ -123,6 +123,23 @@ int tfrec_sort_triples(void *d_temp, size_t temp_bytes, const tfrec_triple_src &
 // ------------------------------------------------------------------------------------------
 #ifdef __HIPCC__
 
+// The value the lane 32 places away holds (v_permlane32_swap: a vector-ALU move, no LDS trip).
+__device__ __forceinline__ uint32_t swap32(uint32_t x, int lane)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return (lane & 32) ? r[0] : r[1];
+}
+
+// Lane exchange of a 32-bit word with the lane whose number differs in bit J (J = 1..32).
+template <int J>
+__device__ __forceinline__ uint32_t xor_lane_u32(uint32_t v, int lane)
+{
+    if constexpr (J == 32) return swap32(v, lane);
+    else if constexpr (J == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    else return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (J << 10) | 0x1f);                           // bit-mask mode, xor J
+}
+
 // Butterfly exchange inside an aligned group of up to 64 lanes.  ds_swizzle's bit-mask mode
 // covers XOR masks below 32 without an address register; mask 32 goes through ds_bpermute.
 template <int MASK>

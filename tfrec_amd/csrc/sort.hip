@@ -247,6 +247,56 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(Src src,
 // (6 to 10 of the up to 91) go through LDS and its barriers.
 constexpr int SMALL_MAX = 8192;
 
+// word i keeps the smaller of (its own, its partner's) when it is the lower index of an ascending pair or the
+// upper index of a descending one
+__device__ __forceinline__ uint64_t bitonic_keep(uint64_t mine, uint64_t other, uint32_t i, uint32_t j, uint32_t k2)
+{
+    const bool take_min = ((i & j) == 0) == ((i & k2) == 0);
+    const bool other_less = other < mine;
+    return (other_less == take_min) ? other : mine;
+}
+
+// one stage (partner distance J inside blocks of K2) of the network; x[r] of thread t is word t*E + r
+template <int E, uint32_t K2, uint32_t J>
+__device__ __forceinline__ void small_sort_stage(uint64_t (&x)[E], uint64_t *e, uint32_t i0, int lane)
+{
+    if constexpr (J < (uint32_t)E) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            if ((r & J) == 0) {
+                const uint64_t a = x[r], b = x[r | J];
+                const bool up = ((i0 + r) & K2) == 0;
+                const bool sw = (a > b) == up;
+                x[r] = sw ? b : a;
+                x[r | J] = sw ? a : b;
+            }
+        }
+    } else if constexpr (J < 64u * E) {
+        constexpr int M = (int)(J / E);                   // partner lane = lane ^ M, same register
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const uint32_t lo = xor_lane_u32<M>((uint32_t)x[r], lane);
+            const uint32_t hi = xor_lane_u32<M>((uint32_t)(x[r] >> 32), lane);
+            x[r] = bitonic_keep(x[r], ((uint64_t)hi << 32) | lo, i0 + r, J, K2);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < E; ++r) e[i0 + r] = x[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < E; ++r) x[r] = bitonic_keep(x[r], e[(i0 + r) ^ J], i0 + r, J, K2);
+        __syncthreads();
+    }
+}
+
+template <int E, uint32_t NP, uint32_t K2, uint32_t J>
+__device__ __forceinline__ void small_sort_stages(uint64_t (&x)[E], uint64_t *e, uint32_t i0, int lane)
+{
+    small_sort_stage<E, K2, J>(x, e, i0, lane);
+    if constexpr (J > 1) small_sort_stages<E, NP, K2, J / 2>(x, e, i0, lane);
+    else if constexpr (K2 < NP) small_sort_stages<E, NP, K2 * 2, K2>(x, e, i0, lane);
+}
+
 template <class Src, int E, int NT>
 __global__ __launch_bounds__(NT) void sort_small_kernel(Src src, uint32_t n, uint32_t *__restrict__ kout, uint32_t *__restrict__ vout)
 {
@@ -267,51 +317,7 @@ __global__ __launch_bounds__(NT) void sort_small_kernel(Src src, uint32_t n, uin
 #pragma unroll
     for (int r = 0; r < E; ++r) x[r] = e[i0 + r];
     __syncthreads();
-
-    // word i keeps the smaller of (its own, its partner's) when it is the lower index of an ascending pair or the
-    // upper index of a descending one
-    auto keep = [&](uint64_t mine, uint64_t other, uint32_t i, uint32_t j, uint32_t k2) {
-        const bool take_min = ((i & j) == 0) == ((i & k2) == 0);
-        const bool other_less = other < mine;
-        return (other_less == take_min) ? other : mine;
-    };
-    for (uint32_t k2 = 2; k2 <= NP; k2 <<= 1) {
-        for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
-            if (j < (uint32_t)E) {
-                // partner inside the thread (j is 1, 2 or 4: spelled out so that x[] stays in registers)
-#pragma unroll
-                for (int J = 1; J < E; J <<= 1) {
-                    if (j == (uint32_t)J) {
-#pragma unroll
-                        for (int r = 0; r < E; ++r) {
-                            if ((r & J) == 0) {
-                                const uint64_t a = x[r], b = x[r | J];
-                                const bool up = ((i0 + r) & k2) == 0;
-                                const bool sw = (a > b) == up;
-                                x[r] = sw ? b : a;
-                                x[r | J] = sw ? a : b;
-                            }
-                        }
-                    }
-                }
-            } else if (j < 64u * E) {
-                const int m = (int)(j / E);                   // partner lane = lane ^ m, same register
-#pragma unroll
-                for (int r = 0; r < E; ++r) {
-                    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x[r], m, 64);
-                    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(x[r] >> 32), m, 64);
-                    x[r] = keep(x[r], ((uint64_t)hi << 32) | lo, i0 + r, j, k2);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < E; ++r) e[i0 + r] = x[r];
-                __syncthreads();
-#pragma unroll
-                for (int r = 0; r < E; ++r) x[r] = keep(x[r], e[(i0 + r) ^ j], i0 + r, j, k2);
-                __syncthreads();
-            }
-        }
-    }
+    small_sort_stages<E, NP, 2, 1>(x, e, i0, (int)(threadIdx.x & 63));
 #pragma unroll
     for (int r = 0; r < E; ++r) e[i0 + r] = x[r];
     __syncthreads();
