@@ -337,6 +337,8 @@ def main():
     ap.add_argument("--item-mode", default="auto", choices=["auto", "dense", "sharded"],
                     help="multi-GPU item table: replicated with one all-reduce of gradient sums per step, or sharded with all-to-all lookups")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend for N>1 (gloo: testing only)")
+    ap.add_argument("--overlap-chunks", type=int, default=None, help="replicated item table: ranges of item ids whose all-reduce "
+                    "overlaps the rest of the item half (default: 2 under RCCL with more than one rank, else 1)")
     ap.add_argument("--force-dist", action="store_true", help="testing: with one rank, still create the process group, so that "
                     "every collective of the multi-GPU path runs (trivially) through the chosen backend")
     ap.add_argument("--single-device", action="store_true", help="testing: every rank uses GPU 0 (needs --backend gloo)")
@@ -420,7 +422,8 @@ def main():
             trainer = None
         else:
             from tfrec_amd.sharded import ShardedBprTrainer
-            trainer = ShardedBprTrainer(dev, U, I, d, lr, reg, seed=2018, device=cuda, item_mode=args.item_mode)
+            trainer = ShardedBprTrainer(dev, U, I, d, lr, reg, seed=2018, device=cuda, item_mode=args.item_mode,
+                                        overlap_chunks=args.overlap_chunks)
             lo, hi = trainer.user_range
             users = (torch.randint(0, hi - lo, (n_batches * B,), device=cuda, generator=gen, dtype=torch.int32) + lo)
             pos = zipf_items(I, n_batches * B, gen, cuda)
@@ -483,7 +486,8 @@ def main():
                        "users": U, "items": I, "factors": d, "batch_per_gpu": B, "global_batch": B * world,
                        "lr": lr, "reg": reg, "resident_batches": n_batches,
                        "parallelism": "single GPU" if trainer is None else (
-                           "user table row-sharded over %d GPUs, item table replicated, one all-reduce of item gradient sums per step" % world
+                           "user table row-sharded over %d GPUs, item table replicated, all-reduce of item gradient sums per step in %d range(s) of item ids"
+                           % (world, trainer.overlap_chunks)
                            if trainer.item_mode == "dense" else "tables row-sharded over %d GPUs, all-to-all lookups per step" % world)},
         }
 

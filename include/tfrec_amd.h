@@ -243,6 +243,14 @@ int tfrec_bpr_dense_grad_step(tfrec_ctx *ctx, int slot, float *d_P, const float 
 int tfrec_bpr_dense_grad_step_v(tfrec_ctx *ctx, int slot, tfrec_utable *t, const float *d_Q, const float *d_b, float *d_G,
                                 int64_t I, const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg, int64_t B,
                                 float lr, float reg, double *d_loss);
+/* The same with the item half run in n_chunks pieces (1..32), one range of ceil(I / n_chunks) item ids after the
+ * other: chunk_done[c] (HIP events the caller created on this device) is recorded on the context's stream when
+ * rows [c * ceil(I / n_chunks), ...) of d_G are complete, so that the caller can start summing those rows over the
+ * GPUs on another stream while the next ranges are still being computed.  The bias part of d_G is complete with
+ * the last event.  Sums of an item are formed in a different association than in the unchunked call (last bits). */
+int tfrec_bpr_dense_grad_step_chunked(tfrec_ctx *ctx, int slot, tfrec_utable *t, const float *d_Q, const float *d_b, float *d_G,
+                                      int64_t I, const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg, int64_t B,
+                                      float lr, float reg, double *d_loss, int n_chunks, void **chunk_done);
 /* y[i] = fma(alpha, x[i], y[i]) for i < n: the plain SGD update (model/BPR.py:48) of a replicated
  * table from a summed gradient table, alpha = -learning rate. */
 int tfrec_axpy(tfrec_ctx *ctx, float *d_y, const float *d_x, float alpha, int64_t n);

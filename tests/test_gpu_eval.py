@@ -115,6 +115,44 @@ def test_ties_break_by_ascending_id(dev):
     assert np.array_equal(ids2.numpy(), ids.numpy())
 
 
+def test_nan_and_infinite_scores_have_a_defined_ranking(dev):
+    """A diverged model: +inf scores rank first (ascending id among them), an item whose score is NaN never
+    enters a list, and a user whose every score is NaN gets an empty list (ids -1, scores -inf) -- in both
+    scoring modes and in the dense top-k (the scoring kernels are built without NaN-honouring comparisons, so this
+    behaviour is pinned here rather than left to the compiler)."""
+    from tfrec_amd.device import SCORE_BF16, SCORE_F32
+    rng = np.random.default_rng(3)
+    U, I, d, k = 70, 900, 32, 20
+    P = rng.normal(size=(U, d)).astype(np.float32)
+    Q = rng.normal(size=(I, d)).astype(np.float32)
+    b = np.zeros(I, np.float32)
+    b[[5, 17]] = np.inf
+    b[33] = -np.inf
+    b[[40, 41]] = np.nan
+    Q[100, 3] = np.nan
+    P[7, :] = np.nan
+    nan_items = {40, 41, 100}
+    eu = dev.array(np.arange(U, dtype=np.int32), np.int32)
+    with np.errstate(invalid="ignore"):
+        R = (P.astype(np.float64) @ Q.T.astype(np.float64) + b).astype(np.float32)
+    finite_best = np.argsort(-np.where(np.isfinite(R), R, -np.inf), axis=1, kind="stable")
+    results = [dev.score_topk(dev.array(P), dev.array(Q), dev.array(b), eu, k, mode=m) for m in (SCORE_F32, SCORE_BF16)]
+    results.append(dev.topk_dense(dev.array(R), k))
+    dev.synchronize()
+    for which, (ids, sc) in enumerate(results):
+        ids, sc = ids.numpy(), sc.numpy()
+        for u in range(U):
+            if u == 7:
+                assert (ids[u] == -1).all() and np.isneginf(sc[u]).all(), which
+                continue
+            assert ids[u, 0] == 5 and ids[u, 1] == 17 and np.isposinf(sc[u, :2]).all(), (which, u)
+            assert not (set(ids[u].tolist()) & nan_items) and 33 not in ids[u], (which, u)
+            assert len(set(ids[u].tolist())) == k and ids[u].min() >= 0 and ids[u].max() < I, (which, u)
+            assert np.isfinite(sc[u, 2:]).all() and (np.diff(sc[u, 2:]) <= 0).all(), (which, u)
+            if which != 1:          # exact arithmetic: the finite part of the list is the float ranking itself
+                assert np.array_equal(ids[u, 2:6], finite_best[u, :4]), (which, u)
+
+
 def test_item_sharded_merge_equals_single_pass(dev):
     rng = np.random.default_rng(4)
     U, I, d, k, G = 300, 9000, 64, 100, 3

@@ -58,6 +58,38 @@ def test_single_rank_sharded_path_matches_unsharded(oracle, item_mode):
     dev.close()
 
 
+@pytest.mark.parametrize("K", [2, 5, 32])
+def test_item_half_in_ranges_of_item_ids_equals_the_whole(K):
+    """The replicated-table step with its item half cut into K ranges of item ids (what the overlapped all-reduce
+    runs on): same parameters as the uncut step, up to the association of the sums; batches large and small
+    (long and short tiles), prepared and not, hot items, ranges that receive nothing."""
+    from tfrec_amd.sharded import ShardedBprTrainer, make_device
+    dev = make_device(0)
+    cuda = torch.device("cuda", 0)
+    U, I, d = 3000, 1003, 64
+    # (a small learning rate: the hottest item collects tens of thousands of summed gradients per step)
+    one = ShardedBprTrainer(dev, U, I, d, 0.0005, 0.05, seed=11, item_mode="dense", overlap_chunks=1)
+    cut = ShardedBprTrainer(dev, U, I, d, 0.0005, 0.05, seed=11, item_mode="dense", overlap_chunks=K)
+    assert cut.overlap_chunks == K and one.overlap_chunks == 1
+    rng = np.random.default_rng(K)
+    batches = []
+    for B, item_hi in ((200000, I), (300, I), (50000, 40), (1, I), (150000, I)):
+        u = rng.integers(0, U, B).astype(np.int32)
+        i = np.minimum((rng.pareto(1.0, B) * 3).astype(np.int64), item_hi - 1).astype(np.int32)      # a few very hot items
+        j = rng.integers(0, item_hi, B).astype(np.int32)
+        batches.append([torch.from_numpy(x).to(cuda) for x in (u, i, j)])
+    for tr in (one, cut):
+        for bt in batches[:4]:
+            tr.step(*bt)
+        tr.prepare(0, *batches[4])
+        tr.step_prepared(0, prepare_next=(1,) + tuple(batches[0]))
+        tr.step_prepared(1)
+    torch.cuda.synchronize()
+    for a, c in ((cut.P, one.P), (cut.Q_full, one.Q_full), (cut.b_full, one.b_full)):
+        np.testing.assert_allclose(a.cpu().numpy(), c.cpu().numpy(), rtol=2e-5, atol=1e-6)
+    dev.close()
+
+
 def _two_rank_worker(rank, world, port, out_dir):
     """Two ranks share the one GPU of the test box; gloo moves the tensors (RCCL needs a GPU per rank)."""
     import os
@@ -71,7 +103,9 @@ def _two_rank_worker(rank, world, port, out_dir):
     dev = make_device(0)
     cuda = torch.device("cuda", 0)
     U, I, d, B, k = 4000, 1500, 64, 30000, 20
-    tr = ShardedBprTrainer(dev, U, I, d, 0.01, 0.05, seed=7, item_mode="dense")
+    # (the item half in three ranges of item ids, each range's rows all-reduced on a second stream as it completes)
+    tr = ShardedBprTrainer(dev, U, I, d, 0.01, 0.05, seed=7, item_mode="dense", overlap_chunks=3)
+    assert tr.overlap_chunks == 3
     rng = np.random.default_rng(1)
     lo, hi = tr.user_range
     batches = []

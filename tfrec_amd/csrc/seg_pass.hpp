@@ -117,8 +117,15 @@ __global__ __launch_bounds__(256) void seg_tile_kernel(Pol pol, const uint32_t *
                                                        const uint32_t *__restrict__ vals, int64_t base, int64_t n,
                                                        float *__restrict__ part_rows, float4 *__restrict__ part_sc,
                                                        uint32_t *__restrict__ tile_flags, int64_t blk_slot0,
-                                                       double *__restrict__ loss_part)
+                                                       double *__restrict__ loss_part, const int64_t *__restrict__ range = nullptr)
 {
+    // range (device memory, optional): the pass covers positions [base + range[0], base + range[1]) only; the grid
+    // was sized for n, workgroups past the end of the range find nothing to do
+    if (range) {
+        base += range[0];
+        n = range[1] - range[0];
+        if ((int64_t)blockIdx.x * (256 / Pol::LPR) * pol_ch<Pol>() >= n) return;      // the whole workgroup lies past the range
+    }
     constexpr int LPR = Pol::LPR, NCH = Pol::NCH, VEC = Pol::VEC;
     using RowT = typename Pol::RowT;
     using G = TileGeom<LPR, pol_ch<Pol>()>;
@@ -251,12 +258,19 @@ __global__ __launch_bounds__(256) void seg_tile_kernel(Pol pol, const uint32_t *
 template <class Pol>
 __global__ __launch_bounds__(256) void seg_fixup_kernel(Pol pol, const uint32_t *__restrict__ keys, int64_t base, int64_t n,
                                                         const float *__restrict__ part_rows, const float4 *__restrict__ part_sc,
-                                                        const uint32_t *__restrict__ tile_flags, int64_t n_tiles, int64_t blk_slot0)
+                                                        const uint32_t *__restrict__ tile_flags, int64_t n_tiles, int64_t blk_slot0,
+                                                        const int64_t *__restrict__ range = nullptr)
 {
     constexpr int LPR = Pol::LPR, NCH = Pol::NCH, VEC = Pol::VEC;
     using RowT = typename Pol::RowT;
     using G = TileGeom<LPR, pol_ch<Pol>()>;
     constexpr int CH = G::CH, GPB = G::GPB;
+    if (range) {
+        base += range[0];
+        n = range[1] - range[0];
+        n_tiles = (n + CH - 1) / CH;
+        if ((int64_t)blockIdx.x * GPB >= n_tiles) return;
+    }
     constexpr int ROWF = LPR * NCH * VEC;
     __shared__ int64_t long_w[GPB];
     __shared__ int long_n;

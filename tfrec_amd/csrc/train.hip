@@ -665,6 +665,7 @@ struct StepWs {
     uint32_t *tile_flags;
     int64_t blk_slot0;       // partial-record slot of workgroup 0's pre-summed partial
     double *loss_part, *scalars;
+    int64_t *bounds;         // [64] positions where the item half changes item range (item pass in pieces)
     int64_t n_tiles_u, n_tiles_i;
     int blocks_u, blocks_i;
 };
@@ -687,6 +688,7 @@ static size_t step_ws_bytes(int64_t B, int d, const RowCfg &c)
     s += tf_align(sizeof(uint32_t) * tiles);
     s += tf_align(sizeof(double) * 4 * (tiles + 8));       // loss partials (<= one per block)
     s += tf_align(sizeof(double) * 16);
+    s += tf_align(sizeof(int64_t) * 64);
     return s + 4096;
 }
 
@@ -720,7 +722,8 @@ static int step_ws_carve(tfrec_ctx *ctx, int64_t B, int d, const RowCfg &c, Step
     w->blk_slot0 = 2 * tiles;
     w->loss_part = (double *)tfrec_ws_take(ctx, sizeof(double) * 4 * (tiles + 8));
     w->scalars = (double *)tfrec_ws_take(ctx, sizeof(double) * 16);
-    TF_REQUIRE(w->scalars != nullptr, TFREC_ENOMEM, "internal: workspace carve failed");
+    w->bounds = (int64_t *)tfrec_ws_take(ctx, sizeof(int64_t) * 64);
+    TF_REQUIRE(w->bounds != nullptr, TFREC_ENOMEM, "internal: workspace carve failed");
     w->n_tiles_u = (B + CH - 1) / CH;
     w->n_tiles_i = (2 * B + CH - 1) / CH;
     w->blocks_u = (int)((w->n_tiles_u + GPB - 1) / GPB);
@@ -748,14 +751,16 @@ static bool all_aligned16(std::initializer_list<const void *> ps)
 
 template <class Pol>
 static int run_pass(tfrec_ctx *ctx, const Pol &pol, const StepWs &w, const uint32_t *keys, const uint32_t *vals, int64_t base,
-                    int64_t n, int64_t n_tiles, int blocks, bool with_loss_part, const char *tile_name, const char *fix_name)
+                    int64_t n, int64_t n_tiles, int blocks, bool with_loss_part, const char *tile_name, const char *fix_name,
+                    const int64_t *d_range = nullptr)
 {
     if (n <= 0) return TFREC_OK;
     seg_tile_kernel<Pol><<<blocks, 256, 0, ctx->stream>>>(pol, keys, vals, base, n, w.part_rows, w.part_sc, w.tile_flags, w.blk_slot0,
-                                                         with_loss_part ? w.loss_part : nullptr);
+                                                         with_loss_part ? w.loss_part : nullptr, d_range);
     TF_HIP(hipGetLastError());
     tfrec_mark(ctx, tile_name);
-    seg_fixup_kernel<Pol><<<blocks, 256, 0, ctx->stream>>>(pol, keys, base, n, w.part_rows, w.part_sc, w.tile_flags, n_tiles, w.blk_slot0);
+    seg_fixup_kernel<Pol><<<blocks, 256, 0, ctx->stream>>>(pol, keys, base, n, w.part_rows, w.part_sc, w.tile_flags, n_tiles, w.blk_slot0,
+                                                          d_range);
     TF_HIP(hipGetLastError());
     tfrec_mark(ctx, fix_name);
     return TFREC_OK;
@@ -795,11 +800,36 @@ __global__ __launch_bounds__(256) void utable_flatten_kernel(float *__restrict__
     }
 }
 
+// Where the item half of a sorted batch changes from one range of item ids to the next: pos[c] = first position
+// (relative to the item half) whose item is >= c * items_per_chunk; pos[n_chunks] = n.  One lane per boundary.
+__global__ void item_chunk_bounds_kernel(const uint32_t *__restrict__ item_keys, int64_t n, uint32_t kmask, uint32_t U,
+                                         uint32_t items_per_chunk, int n_chunks, int64_t *__restrict__ pos)
+{
+    const int c = threadIdx.x;
+    if (c > n_chunks) return;
+    if (c == n_chunks) { pos[c] = n; return; }
+    const uint64_t want = (uint64_t)U + (uint64_t)c * items_per_chunk;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((uint64_t)(item_keys[mid] & kmask) < want) lo = mid + 1; else hi = mid;
+    }
+    pos[c] = lo;
+}
+
+// Item pass in pieces: what a caller passes to have the item half of a step run one range of item ids after the
+// other, with an event recorded on the stream when a range's gradient sums are complete.
+struct ItemChunks {
+    int n = 1;                         // ranges of ceil(I / n) items
+    int64_t I = 0;
+    hipEvent_t *done = nullptr;        // [n]
+};
+
 // the row passes of one BPR step over an already sorted batch; ut: the versioned user table, or null for the
 // plain layout (the pre-step user rows are then staged for the item pass)
 static int bpr_passes(tfrec_ctx *ctx, const tfrec_batch_slot &sl, float *d_P, float *d_Q, float *d_b, int64_t U, int d,
                       float lr, float reg, double *d_loss, bool item_grad_only = false, float *d_gQ = nullptr, float *d_gb = nullptr,
-                      const tfrec_utable *ut = nullptr)
+                      const tfrec_utable *ut = nullptr, const ItemChunks *chunks = nullptr)
 {
     const int64_t B = sl.B;
     const int64_t k0 = sl.next_k;                 // which of the slot's batches this step consumes
@@ -812,6 +842,14 @@ static int bpr_passes(tfrec_ctx *ctx, const tfrec_batch_slot &sl, float *d_P, fl
     BprParams a{d_P, d_Q, d_b, ut ? ut->P2 : nullptr, ut ? ut->ver : nullptr, d_gQ ? d_gQ : d_Q, d_gb ? d_gb : d_b, w.stage, w.sbuf,
                 sl.pair + B * k0, sl.users_raw + B * k0, (uint32_t)U, d, d / cfg.vec, lr, reg, sl.kmask};
     const bool want_loss = d_loss != nullptr;
+    int64_t *d_bounds = nullptr;
+    if (chunks && chunks->n > 1) {
+        TF_REQUIRE(item_grad_only && chunks->n <= 32 && chunks->done, TFREC_EINVAL, "internal: bad item chunking");
+        d_bounds = w.bounds;
+        const uint32_t ipc = (uint32_t)((chunks->I + chunks->n - 1) / chunks->n);
+        item_chunk_bounds_kernel<<<1, 64, 0, ctx->stream>>>(keys + B, 2 * B, sl.kmask, (uint32_t)U, ipc, chunks->n, d_bounds);
+        TF_HIP(hipGetLastError());
+    }
     auto passes = [&]<int LPR, int NCH, int VEC, bool FULL, bool VER, bool SHORT>() -> int {
         if (want_loss) {
             TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, FULL, true, VER, SHORT>{a}, w, keys, vals, 0, B, w.n_tiles_u, w.blocks_u, true,
@@ -821,6 +859,16 @@ static int bpr_passes(tfrec_ctx *ctx, const tfrec_batch_slot &sl, float *d_P, fl
         } else {
             TF_TRY(run_pass(ctx, BprUserPol<LPR, NCH, VEC, FULL, false, VER, SHORT>{a}, w, keys, vals, 0, B, w.n_tiles_u, w.blocks_u, false,
                             "user_tile", "user_fixup"));
+        }
+        if (item_grad_only && chunks && chunks->n > 1) {
+            // one launch pair per range of item ids; the ranges' positions are found on the device, every launch is
+            // sized for the whole item half
+            for (int c = 0; c < chunks->n; ++c) {
+                TF_TRY(run_pass(ctx, BprItemPol<LPR, NCH, VEC, FULL, true, VER, SHORT>{a}, w, keys, vals, B, 2 * B, w.n_tiles_i, w.blocks_i,
+                                false, "item_tile", "item_fixup", d_bounds + c));
+                TF_HIP(hipEventRecord(chunks->done[c], ctx->stream));
+            }
+            return TFREC_OK;
         }
         if (item_grad_only)
             return run_pass(ctx, BprItemPol<LPR, NCH, VEC, FULL, true, VER, SHORT>{a}, w, keys, vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false,
@@ -1137,7 +1185,7 @@ extern "C" int tfrec_bpr_sgd_step_prepared_v(tfrec_ctx *ctx, int slot, tfrec_uta
 // applying Q -= lr*G on every copy is the unsharded step.
 static int dense_grad_step_impl(tfrec_ctx *ctx, int slot, float *d_P, const float *d_Q, const float *d_b, float *d_G, int64_t U,
                                 int64_t I, int d, const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg, int64_t B,
-                                float lr, float reg, double *d_loss, const tfrec_utable *ut)
+                                float lr, float reg, double *d_loss, const tfrec_utable *ut, const ItemChunks *chunks = nullptr)
 {
     TF_REQUIRE(slot >= -1 && slot <= 1, TFREC_EINVAL, "slot must be -1 (sort now), 0 or 1");
     TF_REQUIRE(d_G != nullptr && ((uintptr_t)d_G & 15u) == 0, TFREC_EINVAL, "gradient table missing or not 16-byte aligned");
@@ -1150,18 +1198,20 @@ static int dense_grad_step_impl(tfrec_ctx *ctx, int slot, float *d_P, const floa
     if (slot < 0) {
         if (B == 0) {
             if (d_loss) TF_HIP(hipMemsetAsync(d_loss, 0, 2 * sizeof(double), ctx->stream));
+            if (chunks)          // nothing to add: the zeroed table is complete
+                for (int c = 0; c < chunks->n; ++c) TF_HIP(hipEventRecord(chunks->done[c], ctx->stream));
             return TFREC_OK;
         }
         tfrec_batch_slot &sl = ctx->slots[2];
         TF_TRY(slot_prepare(ctx, sl, ctx->stream, d_users, d_pos, d_neg, B, U, I));
         tfrec_mark(ctx, "index");
-        return bpr_passes(ctx, sl, d_P, const_cast<float *>(d_Q), const_cast<float *>(d_b), U, d, lr, reg, d_loss, true, gQ, gb, ut);
+        return bpr_passes(ctx, sl, d_P, const_cast<float *>(d_Q), const_cast<float *>(d_b), U, d, lr, reg, d_loss, true, gQ, gb, ut, chunks);
     }
     tfrec_batch_slot &sl = ctx->slots[slot];
     TF_REQUIRE(sl.B >= 1, TFREC_EINVAL, "slot %d holds no prepared batch", slot);
     TF_REQUIRE(sl.U == U && sl.I == I, TFREC_EINVAL, "slot %d was prepared for a %lldx%lld model", slot, (long long)sl.U, (long long)sl.I);
     TF_HIP(hipStreamWaitEvent(ctx->stream, sl.ready, 0));
-    const int rc = bpr_passes(ctx, sl, d_P, const_cast<float *>(d_Q), const_cast<float *>(d_b), U, d, lr, reg, d_loss, true, gQ, gb, ut);
+    const int rc = bpr_passes(ctx, sl, d_P, const_cast<float *>(d_Q), const_cast<float *>(d_b), U, d, lr, reg, d_loss, true, gQ, gb, ut, chunks);
     if (++sl.next_k >= sl.K) {
         TF_HIP(hipEventRecord(sl.released, ctx->stream));
         sl.has_released = true;
@@ -1185,6 +1235,25 @@ extern "C" int tfrec_bpr_dense_grad_step_v(tfrec_ctx *ctx, int slot, tfrec_utabl
     TF_TRY(tfrec_ctx_enter(ctx));
     TF_TRY(check_utable(ctx, t));
     return dense_grad_step_impl(ctx, slot, t->P, d_Q, d_b, d_G, t->U, I, t->d, d_users, d_pos, d_neg, B, lr, reg, d_loss, t);
+}
+
+extern "C" int tfrec_bpr_dense_grad_step_chunked(tfrec_ctx *ctx, int slot, tfrec_utable *t, const float *d_Q, const float *d_b, float *d_G,
+                                                 int64_t I, const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg,
+                                                 int64_t B, float lr, float reg, double *d_loss, int n_chunks, void **chunk_done)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_TRY(check_utable(ctx, t));
+    TF_REQUIRE(n_chunks >= 1 && n_chunks <= 32, TFREC_EINVAL, "n_chunks must be 1..32, got %d", n_chunks);
+    TF_REQUIRE(chunk_done != nullptr, TFREC_EINVAL, "null event array");
+    for (int c = 0; c < n_chunks; ++c) TF_REQUIRE(chunk_done[c] != nullptr, TFREC_EINVAL, "event %d is null", c);
+    ItemChunks ch;
+    ch.n = n_chunks; ch.I = I; ch.done = reinterpret_cast<hipEvent_t *>(chunk_done);
+    if (n_chunks == 1) {
+        TF_TRY(dense_grad_step_impl(ctx, slot, t->P, d_Q, d_b, d_G, t->U, I, t->d, d_users, d_pos, d_neg, B, lr, reg, d_loss, t));
+        TF_HIP(hipEventRecord(ch.done[0], ctx->stream));
+        return TFREC_OK;
+    }
+    return dense_grad_step_impl(ctx, slot, t->P, d_Q, d_b, d_G, t->U, I, t->d, d_users, d_pos, d_neg, B, lr, reg, d_loss, t, &ch);
 }
 
 __global__ __launch_bounds__(256) void axpy_kernel(float *__restrict__ y, const float *__restrict__ x, float alpha, int64_t n4, int64_t n)

@@ -271,6 +271,16 @@ class Device:
         _lib.check(self.lib.tfrec_bpr_dense_grad_step_v(self.h, int(slot), ut.h, _ptr(Q), _ptr(b), _ptr(G), I, _ptr(users), _ptr(pos),
                                                         _ptr(neg), B, float(lr), float(reg), _ptr(loss)))
 
+    def bpr_dense_grad_step_chunked(self, ut, Q, b, G, users, pos, neg, lr, reg, chunk_events, slot=-1, loss=None):
+        """``bpr_dense_grad_step_v`` with the item half in ``len(chunk_events)`` ranges of item ids; ``chunk_events``
+        are raw HIP event handles (ints), recorded on the context's stream as the ranges' rows of ``G`` complete."""
+        I = _shape(Q)[0]
+        B = _shape(users)[0] if users is not None else 0
+        n = len(chunk_events)
+        evs = (C.c_void_p * n)(*[C.c_void_p(int(e)) for e in chunk_events])
+        _lib.check(self.lib.tfrec_bpr_dense_grad_step_chunked(self.h, int(slot), ut.h, _ptr(Q), _ptr(b), _ptr(G), I, _ptr(users), _ptr(pos),
+                                                              _ptr(neg), B, float(lr), float(reg), _ptr(loss), n, C.cast(evs, C.c_void_p)))
+
     def bpr_sgd_step_noalloc(self, P, Q, b, users, pos, neg, lr, reg, loss=None):
         """``bpr_sgd_step`` for callers that cannot allocate: all device scratch comes from a fixed array inside
         the library (16 MiB per GPU); larger batches raise NotImplementedError.  Calls that overlap on one GPU race."""
