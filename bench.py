@@ -156,10 +156,8 @@ def large_shape(dev, cuda, U=10_000_000, I=2_000_000, d=128, B=1 << 22, steps=10
         return users[o:o + B], pos[o:o + B], neg[o:o + B]
 
     def bpr(s):
-        # as in the headline loop: the index of batch s+1 is sorted on the auxiliary stream beside the row passes of batch s
-        dev.prepare_batches((s + 1) & 1, U, I, *grp(s + 1), 1)
-        dev.bpr_sgd_step_prepared_v(s & 1, ut, Q, b, 0.01, 0.05)
-    dev.prepare_batches(0, U, I, *grp(0), 1)
+        # (un-pipelined: at this shape sorting the next batch beside the row passes costs more than it hides)
+        dev.bpr_sgd_step_v(ut, Q, b, *grp(s), 0.01, 0.05)
     for s in range(4):
         bpr(s)
     e0.record()

@@ -169,7 +169,12 @@ __global__ __launch_bounds__(256) void seg_tile_kernel(Pol pol, const uint32_t *
         static_assert(CH % DEPTH == 0, "a tile holds a whole number of gather groups");
         uint32_t cur_key = ent[g][0].x;
         bool lead_open = (cur_key == key_prev);
-        typename Pol::Seg seg = pol.load_seg(cur_key, gl);
+        // (a policy whose destination row depends on more than the key defines load_seg_en(entry, gl))
+        auto seg_of = [&](const uint4 &en_) {
+            if constexpr (requires { pol.load_seg_en(en_, gl); }) return pol.load_seg_en(en_, gl);
+            else return pol.load_seg(en_.x, gl);
+        };
+        typename Pol::Seg seg = seg_of(ent[g][0]);
         uint32_t seg_key = cur_key;          // key of the most recently requested segment row
         // WHOLE: the tile has all CH occurrences (every tile but the last one of a pass), no bounds tests.
         auto run = [&]<bool WHOLE>() {
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(256) void seg_tile_kernel(Pol pol, const uint32_t *
                 }
 #pragma unroll
                 for (int q = 0; q < DEPTH; ++q) {
-                    if (en[q].x != seg_key) sg[q] = pol.load_seg(en[q].x, gl);
+                    if (en[q].x != seg_key) sg[q] = seg_of(en[q]);
                     seg_key = en[q].x;
                 }
 #pragma unroll

@@ -73,7 +73,9 @@ struct BprUserPol {
     using DM = RowDims<LPR_, NCH_, VEC_, FULL_>;
     using Loss = LossAcc<LOSS ? 2 : 0>;
     BprParams a;
-    struct Occ { RowT p, qi, qj; float bi, bj; };
+    // The user's row is read once per run of the user's occurrences (they are adjacent in the sorted order), not once
+    // per occurrence: it rides in the segment state, the occurrence brings only the two item rows.
+    struct Occ { RowT qi, qj; float bi, bj; };
     struct Seg { RowT p; };
 
     // .y = occurrence id; its top bit carries the row's version (occurrence ids stay below 2^30)
@@ -86,34 +88,35 @@ struct BprUserPol {
     __device__ __forceinline__ Occ load_occ(uint4 en, int gl) const
     {
         Occ o;
-        const float *src = (VER && (en.y >> 31)) ? a.P2 : a.P;
-        o.p = RowT::load(src + (size_t)(en.x & a.kmask) * DM::d(a.d), gl, DM::nchunk(a.nchunk));
         o.qi = RowT::load(a.Q + (size_t)en.z * DM::d(a.d), gl, DM::nchunk(a.nchunk));
         o.qj = RowT::load(a.Q + (size_t)en.w * DM::d(a.d), gl, DM::nchunk(a.nchunk));
         o.bi = a.b[en.z];
         o.bj = a.b[en.w];
         return o;
     }
-    __device__ __forceinline__ Seg load_seg(uint32_t, int) const { return Seg{RowT::zero()}; }
+    __device__ __forceinline__ Seg load_seg_en(uint4 en, int gl) const
+    {
+        const float *src = (VER && (en.y >> 31)) ? a.P2 : a.P;
+        return Seg{RowT::load(src + (size_t)(en.x & a.kmask) * DM::d(a.d), gl, DM::nchunk(a.nchunk))};
+    }
     __device__ __forceinline__ void compute(Seg &seg, const Occ &o, uint4 en, Acc<RowT> &acc, Loss &loss, int gl) const
     {
         const RowT diff = o.qi - o.qj;
-        const float x = group_sum<LPR_>(o.p.dot_partial(diff)) + (o.bi - o.bj);
+        const float x = group_sum<LPR_>(seg.p.dot_partial(diff)) + (o.bi - o.bj);
         const float z = x + 1e-7f;
         const float s = sigmoid_neg(z);
         acc.v.fma(s, diff);          // user gradient is  -sum s*(q_i - q_j) + n*reg*p
         acc.cnt += 1;
-        seg.p = o.p;
         const uint32_t t = VER ? (en.y & 0x7fffffffu) : en.y;
         if constexpr (VER) {
             // what the item pass needs from this triple in one 8-byte record: s, and where the pre-step user row is
             if (gl == 0) reinterpret_cast<uint2 *>(a.sbuf)[t] = make_uint2(__float_as_uint(s), (en.x & a.kmask) | (en.y & 0x80000000u));
         } else {
-            o.p.store(a.stage + (size_t)t * DM::d(a.d), gl, DM::nchunk(a.nchunk));
+            seg.p.store(a.stage + (size_t)t * DM::d(a.d), gl, DM::nchunk(a.nchunk));
             if (gl == 0) a.sbuf[t] = s;
         }
         if constexpr (LOSS) {
-            float r = o.p.dot_partial(o.p) + o.qi.dot_partial(o.qi) + o.qj.dot_partial(o.qj);
+            float r = seg.p.dot_partial(seg.p) + o.qi.dot_partial(o.qi) + o.qj.dot_partial(o.qj);
             if (gl == 0) {
                 loss.t[0] += softplus_neg(z);
                 r += o.bi * o.bi + o.bj * o.bj;
