@@ -293,8 +293,9 @@ struct AprUser1Pol {
     using DM = RowDims<LPR_, NCH_, VEC_, FULL_>;
     using Loss = LossAcc<0>;
     AprParams a;
-    struct Occ { RowT p, qi, qj; float bi, bj; };
-    struct Seg { int unused; };
+    // (the user's row is read once per run of the user's occurrences: it rides in the segment state)
+    struct Occ { RowT qi, qj; float bi, bj; };
+    struct Seg { RowT p; };
     __device__ __forceinline__ uint4 entry(uint32_t key, uint32_t val, int64_t) const
     {
         const uint2 ij = a.pair[val];
@@ -303,18 +304,20 @@ struct AprUser1Pol {
     __device__ __forceinline__ Occ load_occ(uint4 en, int gl) const
     {
         Occ o;
-        o.p = RowT::load(a.P + (size_t)en.x * DM::d(a.d), gl, DM::nchunk(a.nchunk));
         o.qi = RowT::load(a.Q + (size_t)en.z * DM::d(a.d), gl, DM::nchunk(a.nchunk));
         o.qj = RowT::load(a.Q + (size_t)en.w * DM::d(a.d), gl, DM::nchunk(a.nchunk));
         o.bi = a.b[en.z];
         o.bj = a.b[en.w];
         return o;
     }
-    __device__ __forceinline__ Seg load_seg(uint32_t, int) const { return Seg{0}; }
-    __device__ __forceinline__ void compute(Seg &, const Occ &o, uint4 en, Acc<RowT> &acc, Loss &, int gl) const
+    __device__ __forceinline__ Seg load_seg(uint32_t key, int gl) const
+    {
+        return Seg{RowT::load(a.P + (size_t)key * DM::d(a.d), gl, DM::nchunk(a.nchunk))};
+    }
+    __device__ __forceinline__ void compute(Seg &seg, const Occ &o, uint4 en, Acc<RowT> &acc, Loss &, int gl) const
     {
         const RowT diff = o.qi - o.qj;
-        const float r = group_sum<LPR_>(o.p.dot_partial(diff)) + (o.bi - o.bj);
+        const float r = group_sum<LPR_>(seg.p.dot_partial(diff)) + (o.bi - o.bj);
         const float s = clip_sigmoid_neg(r);
         acc.v.fma(-s, diff);         // g_P = -sum s*(q_i - q_j)
         acc.cnt += 1;
@@ -383,8 +386,9 @@ struct AprUser2Pol {
     using DM = RowDims<LPR_, NCH_, VEC_, FULL_>;
     using Loss = LossAcc<LOSS ? 3 : 0>;
     AprParams a;
-    struct Occ { RowT p, dp, qi, qj, dqi, dqj; float bi, bj, dbi, dbj; };
-    struct Seg { RowT p; };
+    // (the user's row and its delta row are read once per run of the user's occurrences)
+    struct Occ { RowT qi, qj, dqi, dqj; float bi, bj, dbi, dbj; };
+    struct Seg { RowT p, dp; };
     __device__ __forceinline__ uint4 entry(uint32_t key, uint32_t val, int64_t) const
     {
         const uint2 ij = a.pair[val];
@@ -393,8 +397,6 @@ struct AprUser2Pol {
     __device__ __forceinline__ Occ load_occ(uint4 en, int gl) const
     {
         Occ o;
-        o.p = RowT::load(a.P + (size_t)en.x * DM::d(a.d), gl, DM::nchunk(a.nchunk));
-        o.dp = RowT::load(a.dP + (size_t)en.x * DM::d(a.d), gl, DM::nchunk(a.nchunk));
         o.qi = RowT::load(a.Q + (size_t)en.z * DM::d(a.d), gl, DM::nchunk(a.nchunk));
         o.qj = RowT::load(a.Q + (size_t)en.w * DM::d(a.d), gl, DM::nchunk(a.nchunk));
         o.dqi = RowT::load(a.dQ + (size_t)en.z * DM::d(a.d), gl, DM::nchunk(a.nchunk));
@@ -403,30 +405,33 @@ struct AprUser2Pol {
         o.dbi = a.db[en.z]; o.dbj = a.db[en.w];
         return o;
     }
-    __device__ __forceinline__ Seg load_seg(uint32_t, int) const { return Seg{RowT::zero()}; }
+    __device__ __forceinline__ Seg load_seg(uint32_t key, int gl) const
+    {
+        return Seg{RowT::load(a.P + (size_t)key * DM::d(a.d), gl, DM::nchunk(a.nchunk)),
+                   RowT::load(a.dP + (size_t)key * DM::d(a.d), gl, DM::nchunk(a.nchunk))};
+    }
     __device__ __forceinline__ void compute(Seg &seg, const Occ &o, uint4 en, Acc<RowT> &acc, Loss &loss, int gl) const
     {
         const RowT diff = o.qi - o.qj;
-        const RowT pa = o.p + o.dp;
+        const RowT pa = seg.p + seg.dp;
         const RowT diffa = (o.qi + o.dqi) - (o.qj + o.dqj);
-        const float r = group_sum<LPR_>(o.p.dot_partial(diff)) + (o.bi - o.bj);
+        const float r = group_sum<LPR_>(seg.p.dot_partial(diff)) + (o.bi - o.bj);
         const float ra = group_sum<LPR_>(pa.dot_partial(diffa)) + ((o.bi + o.dbi) - (o.bj + o.dbj));
         const float s = clip_sigmoid_neg(r);
         const float sa = a.reg_adv * clip_sigmoid_neg(ra);
         // G_P += -s*(q_i-q_j) - sa*(q_i+dq_i - q_j-dq_j) + creg*p
         acc.v.fma(-s, diff);
         acc.v.fma(-sa, diffa);
-        acc.v.fma(a.reg_coef, o.p);
+        acc.v.fma(a.reg_coef, seg.p);
         acc.cnt += 1;
-        seg.p = o.p;
         // what the item side needs from this triple: c = s*p + sa*(p+dp)  and  s+sa
         RowT c = RowT::zero();
-        c.fma(s, o.p);
+        c.fma(s, seg.p);
         c.fma(sa, pa);
         c.store(a.stage + (size_t)en.y * DM::d(a.d), gl, DM::nchunk(a.nchunk));
         if (gl == 0) a.sbuf[en.y] = s + sa;
         if constexpr (LOSS) {
-            float m = o.p.dot_partial(o.p) + o.qi.dot_partial(o.qi) + o.qj.dot_partial(o.qj);
+            float m = seg.p.dot_partial(seg.p) + o.qi.dot_partial(o.qi) + o.qj.dot_partial(o.qj);
             if (gl == 0) {
                 loss.t[0] += clip_softplus_neg(r);
                 loss.t[1] += clip_softplus_neg(ra);
