@@ -596,8 +596,33 @@ def main():
                 "dominant_phase_algorithmic_GBs": B * (16 * d + 20) / (acc[dom] * 1e-3) / 1e9 if dom == "user_tile" else None,
             }
             if not args.no_extras:
-                # the reference batch size (conf/BPR.ini:4: 512 triples per step): five short kernels, latency-bound
+                # positives uniform over the items instead of Zipf: the bound without hot rows (fewer duplicates,
+                # fewer cache hits on item rows)
                 e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                upos = torch.randint(0, I, (4 * B,), device=cuda, generator=gen, dtype=torch.int32)
+                ut_u = dev.user_table(P) if ut is not None else None
+
+                def ustep(s):
+                    o = (s % 4) * B
+                    if ut_u is not None:
+                        dev.bpr_sgd_step_v(ut_u, Q, b, users[o:o + B], upos[o:o + B], neg[o:o + B], lr, reg)
+                    else:
+                        dev.bpr_sgd_step(P, Q, b, users[o:o + B], upos[o:o + B], neg[o:o + B], lr, reg)
+                for s in range(4):
+                    ustep(s)
+                e2.record(stream)
+                for s in range(20):
+                    ustep(s)
+                e3.record(stream)
+                torch.cuda.synchronize()
+                if ut_u is not None:
+                    ut_u.close()
+                ums = e2.elapsed_time(e3) / 20
+                out["uniform_items_step"] = {"ms_per_step": ums, "triples_per_s": B / (ums * 1e-3),
+                                             "frac": B * alg_bytes_per_triple / (ums * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                             "note": "un-pipelined step, positives uniform over the items (no hot rows)"}
+                del upos
+                # the reference batch size (conf/BPR.ini:4: 512 triples per step): five short kernels, latency-bound
                 small = 512
                 ref = {}
                 for name, fn in (("bpr_sgd_step", dev.bpr_sgd_step), ("bpr_sgd_step_noalloc", dev.bpr_sgd_step_noalloc)):

@@ -162,6 +162,12 @@ void tfrec_marks_reset(tfrec_ctx *ctx) { ctx->n_marks = 0; }
 
 void tfrec_mark(tfrec_ctx *ctx, const char *name)
 {
+#ifdef TF_DEBUG_SYNC
+    // developer builds: wait for every phase and say so, to find the one that never ends
+    TF_DBG("waiting for %s", name);
+    const hipError_t dbg = hipStreamSynchronize(ctx->stream);
+    TF_DBG("%s: %s", name, hipGetErrorString(dbg));
+#endif
     if (!ctx->profile || ctx->n_marks >= tfrec_ctx::MAX_MARKS) return;
     const int i = ctx->n_marks;
     if (!ctx->marks[i] && hipEventCreate(&ctx->marks[i]) != hipSuccess) return;

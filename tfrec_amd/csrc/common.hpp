@@ -118,6 +118,14 @@ struct tfrec_triple_src {
 int tfrec_sort_triples(void *d_temp, size_t temp_bytes, const tfrec_triple_src &src, uint32_t *keys_out, uint32_t *vals_out,
                        int end_bit, hipStream_t stream);
 
+// developer builds (-DTF_DEBUG_SYNC): a line per step of the calls under investigation, appended to a file
+#ifdef TF_DEBUG_SYNC
+#include <cstdio>
+#define TF_DBG(...) do { FILE *f_ = fopen("gpurun_out/tfrec_dbg.log", "a"); if (f_) { fprintf(f_, __VA_ARGS__); fputc('\n', f_); fclose(f_); } } while (0)
+#else
+#define TF_DBG(...) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------

@@ -1124,11 +1124,10 @@ extern "C" int tfrec_batch_prepare_many(tfrec_ctx *ctx, int slot, int64_t U, int
     TF_REQUIRE(U > 0 && I > 0 && U < (1ll << 31) && I < (1ll << 31), TFREC_EINVAL, "bad table shape");
     TF_REQUIRE(B >= 1 && B < (1ll << 30) && d_users && d_pos && d_neg, TFREC_EINVAL, "bad batch");
     if (!ctx->aux_stream) {
-        // The index kernels are short and latency-bound, the row passes they run beside are long and
-        // fill the device: at the highest priority their workgroups are placed as soon as a slot frees.
-        int least = 0, greatest = 0;
-        TF_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        TF_HIP(hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, greatest));
+        // An ordinary stream, not a high-priority one: a high-priority stream whose next packet waits for an event
+        // of the main stream was seen to stall the main stream itself now and then (the wait at the front of the
+        // favoured queue kept the event's own marker from running), and the priority bought no throughput.
+        TF_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
     }
     tfrec_batch_slot &sl = ctx->slots[slot];
     if (!sl.ready) TF_HIP(hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
