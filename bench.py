@@ -316,7 +316,7 @@ def launch_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--steps", type=int, default=600)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1 << 22, help="triples per step per GPU")
     ap.add_argument("--users", type=int, default=1_000_000)
