@@ -90,6 +90,26 @@ def test_item_half_in_ranges_of_item_ids_equals_the_whole(K):
     dev.close()
 
 
+def test_chunked_step_rejects_bad_event_lists():
+    """The chunked entry point refuses an empty or oversized event list and a null event, and says why."""
+    from tfrec_amd.sharded import make_device
+    dev = make_device(0)
+    cuda = torch.device("cuda", 0)
+    U, I, d, B = 50, 40, 8, 30
+    P = torch.zeros(U, d, device=cuda); Q = torch.zeros(I, d, device=cuda); b = torch.zeros(I, device=cuda)
+    G = torch.zeros(I * (d + 1), device=cuda)
+    u = torch.zeros(B, dtype=torch.int32, device=cuda)
+    ut = dev.user_table(P)
+    ev = torch.cuda.Event(); ev.record()
+    for events in ([], [ev.cuda_event] * 33, [0]):
+        with pytest.raises(ValueError):
+            dev.bpr_dense_grad_step_chunked(ut, Q, b, G, u, u, u, 0.01, 0.05, events)
+    dev.bpr_dense_grad_step_chunked(ut, Q, b, G, u, u, u, 0.01, 0.05, [ev.cuda_event])      # one range = the unchunked step
+    dev.synchronize()
+    ut.close()
+    dev.close()
+
+
 def _two_rank_worker(rank, world, port, out_dir):
     """Two ranks share the one GPU of the test box; gloo moves the tensors (RCCL needs a GPU per rank)."""
     import os
