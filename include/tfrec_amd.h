@@ -216,6 +216,9 @@ int tfrec_rows_sgd_apply(tfrec_ctx *ctx, float *d_Q, float *d_b, int64_t I, int 
  * tfrec_batch_prepare(slot, U, Ic, ...): the sort then runs beside the all-to-all that fetches the rows. */
 int tfrec_bpr_grad_step_prepared(tfrec_ctx *ctx, int slot, float *d_P, float *d_Qc, float *d_bc,
                                  int64_t U, int64_t Ic, int d, float lr, float reg, double *d_loss);
+/* The same on a versioned user table (see tfrec_utable): the user shard's pre-step rows are not staged. */
+int tfrec_bpr_grad_step_prepared_v(tfrec_ctx *ctx, int slot, tfrec_utable *t, float *d_Qc, float *d_bc, int64_t Ic,
+                                   float lr, float reg, double *d_loss);
 /* The requester side of the lookup: the distinct items of a batch (d_pos / d_neg, global ids below I), ascending --
  * hence grouped by owner when owner r holds items [r * items_per_owner, (r + 1) * items_per_owner) -- in d_uniq
  * (room for min(2B, I) ids), the slot of every triple's items in that list (d_pos_slot, d_neg_slot), the number of

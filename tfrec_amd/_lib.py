@@ -64,6 +64,7 @@ SIGNATURES = {
     "tfrec_bpr_grad_step": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _i64, _f, _f, _p]),
     "tfrec_rows_sgd_apply": (_int, [_p, _p, _p, _i64, _int, _p, _p, _p, _i64, _f]),
     "tfrec_bpr_grad_step_prepared": (_int, [_p, _int, _p, _p, _p, _i64, _i64, _int, _f, _f, _p]),
+    "tfrec_bpr_grad_step_prepared_v": (_int, [_p, _int, _p, _p, _p, _i64, _f, _f, _p]),
     "tfrec_items_dedup": (_int, [_p, _p, _p, _i64, _i64, _i64, _int, _p, _p, _p, _p, _p]),
     "tfrec_rows_gather": (_int, [_p, _p, _p, _i64, _int, _p, _i64, _p, _p]),
     "tfrec_bpr_dense_grad_step": (_int, [_p, _int, _p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _i64, _f, _f, _p]),

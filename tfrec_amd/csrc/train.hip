@@ -1178,6 +1178,14 @@ extern "C" int tfrec_bpr_grad_step_prepared(tfrec_ctx *ctx, int slot, float *d_P
     return step_prepared_impl(ctx, slot, d_P, d_Qc, d_bc, U, Ic, d, lr, reg, d_loss, nullptr, true);
 }
 
+extern "C" int tfrec_bpr_grad_step_prepared_v(tfrec_ctx *ctx, int slot, tfrec_utable *t, float *d_Qc, float *d_bc, int64_t Ic, float lr,
+                                              float reg, double *d_loss)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_TRY(check_utable(ctx, t));
+    return step_prepared_impl(ctx, slot, t->P, d_Qc, d_bc, t->U, Ic, t->d, lr, reg, d_loss, t, true);
+}
+
 extern "C" int tfrec_bpr_sgd_step_prepared_v(tfrec_ctx *ctx, int slot, tfrec_utable *t, float *d_Q, float *d_b, int64_t I, float lr,
                                              float reg, double *d_loss)
 {

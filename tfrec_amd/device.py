@@ -323,6 +323,11 @@ class Device:
         _lib.check(self.lib.tfrec_bpr_grad_step_prepared(self.h, int(slot), _ptr(P), _ptr(Qc), _ptr(bc), U, Ic, d, float(lr), float(reg),
                                                          _ptr(loss)))
 
+    def bpr_grad_step_prepared_v(self, slot, ut, Qc, bc, lr, reg, loss=None):
+        """``bpr_grad_step_prepared`` on a versioned user table."""
+        Ic = _shape(Qc)[0]
+        _lib.check(self.lib.tfrec_bpr_grad_step_prepared_v(self.h, int(slot), ut.h, _ptr(Qc), _ptr(bc), Ic, float(lr), float(reg), _ptr(loss)))
+
     def items_dedup(self, pos, neg, I, items_per_owner, n_owners, uniq, pos_slot, neg_slot, counts, n_uniq=None):
         """Distinct items of a batch (ascending), every triple's slots in that list, distinct items per owner."""
         B = _shape(pos)[0]

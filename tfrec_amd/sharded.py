@@ -100,8 +100,11 @@ class HipBackend:
     def __init__(self, dev):
         self.dev = dev
 
-    def bpr_grad_step(self, P, Qc, bc, users, pos_slot, neg_slot, lr, reg, slot=-1):
-        if slot >= 0:
+    def bpr_grad_step(self, P, Qc, bc, users, pos_slot, neg_slot, lr, reg, slot=-1, ut=None):
+        """``ut``: the versioned table over ``P`` (used when the batch was prepared; ``P`` is then not read here)."""
+        if slot >= 0 and ut is not None:
+            self.dev.bpr_grad_step_prepared_v(slot, ut, Qc, bc, lr, reg)
+        elif slot >= 0:
             self.dev.bpr_grad_step_prepared(slot, P, Qc, bc, lr, reg)
         else:
             self.dev.bpr_grad_step(P, Qc, bc, users, pos_slot, neg_slot, lr, reg)
@@ -262,9 +265,9 @@ class ShardedBprTrainer:
         # model/base/MatrixFactorization.py:17-21; the stream of random numbers is that of the unsharded
         # table, so the shards of any world size assemble into the same initial model
         self._P = self._init_rows(self.U, self.user_range, seed * 2 + 1)
-        # replicated item table + a backend that offers it: the user shard is a versioned table (no staging of
-        # pre-step user rows in the step); reading ``self.P`` flattens it first
-        self._ut = self.backend.user_table(self._P) if item_mode == "dense" and hasattr(self.backend, "user_table") and nu > 0 else None
+        # a backend that offers it: the user shard is a versioned table (no staging of pre-step user rows in the
+        # step); reading ``self.P`` flattens it first
+        self._ut = self.backend.user_table(self._P) if hasattr(self.backend, "user_table") and nu > 0 else None
         self._ut_dirty = False
         if item_mode == "dense":
             # [Q | b] in one flat buffer, so that one all-reduce and one update cover both
@@ -428,7 +431,10 @@ class ShardedBprTrainer:
         rows, bias = be.rows_gather(self.Q, self.b, local)
         Qc, bc = self._a2a(rows, rc, sc), self._a2a(bias, rc, sc)
         # (3) local step: P shard updated in place, Qc / bc turned into gradient sums
-        if B > 0:
+        if B > 0 and ahead and self._ut is not None:
+            be.bpr_grad_step(self._P, Qc, bc, plan["users"], plan["pos_slot"], plan["neg_slot"], self.lr, self.reg, slot=slot, ut=self._ut)
+            self._ut_dirty = True
+        elif B > 0:
             be.bpr_grad_step(self.P, Qc, bc, plan["users"], plan["pos_slot"], plan["neg_slot"], self.lr, self.reg, slot=slot if ahead else -1)
         # (4) gradient sums back to the owners, who add them in rank order and apply
         gr, gb = self._a2a(Qc, sc, rc), self._a2a(bc, sc, rc)
