@@ -442,8 +442,14 @@ def main():
                     trainer.step_prepared(k & 1, prepare_next=((k + 1) & 1,) + tuple(batch(k + 1)))
                     state["next"] = k + 1
             else:
+                # every table sharded: the lookups of the next n_batches steps are planned together (de-duplication
+                # on the device, one exchange of all the counts, one host read), as an epoch loop does
+                plans = []
+
                 def step(s):
-                    trainer.step(*batch(s))
+                    if not plans:
+                        plans.extend(trainer.plan_steps([batch(s + i) for i in range(n_batches)]))
+                    trainer.step_planned(plans.pop(0), slot=s & 1)
 
         def max_over_ranks(x):
             # (a host tensor under gloo, whose handling of device tensors is unreliable with ranks that share a GPU)
