@@ -81,6 +81,36 @@ def test_bpr_step_vs_oracle(dev, oracle, U, I, d, B, kind):
     assert np.array_equal(P1, P2) and np.array_equal(Q1, Q2) and np.array_equal(b1, b2)
 
 
+@pytest.mark.parametrize("B", [1, 2, 85, 86, 170, 171, 341, 342, 682, 683, 1365, 1366, 2730, 2731])
+def test_bpr_step_at_the_size_classes_of_the_single_workgroup_sort(dev, oracle, B):
+    """3B pairs on either side of every size class of the one-workgroup index sort (256, 512, 1024, 2048, 4096, 8192
+    pairs) and of its hand-over to the radix passes: the step equals the oracle's; and two such batches sorted
+    together (batch number above the row id in the keys) give, consumed one after the other, what two plain steps give."""
+    rng = np.random.default_rng(B)
+    U, I, d = 97, 61, 16
+    P = rng.uniform(-0.3, 0.3, (U, d)).astype(np.float32)
+    Q = rng.uniform(-0.3, 0.3, (I, d)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, I).astype(np.float32)
+    u, i, j = [rng.integers(0, n, 2 * B).astype(np.int32) for n in (U, I, I)]
+    Po, Qo, bo = P.copy(), Q.copy(), b.copy()
+    oracle.bpr_step(Po, Qo, bo, u[:B], i[:B], j[:B], 0.01, 0.05)
+    P1, Q1, b1, _ = run_bpr(dev, P, Q, b, u[:B], i[:B], j[:B], 0.01, 0.05)
+    for new, ref, old in ((P1, Po, P), (Q1, Qo, Q), (b1, bo, b)):
+        scale = max(np.abs(ref - old).max(), 1e-3)
+        assert np.abs(new - ref).max() <= 1e-5 * scale + 2e-7 * np.abs(ref).max()
+    a = [dev.array(x) for x in (P, Q, b)]
+    du, di, dj = dev.array(u, np.int32), dev.array(i, np.int32), dev.array(j, np.int32)
+    for s in range(2):
+        dev.bpr_sgd_step(*a, du.view(s * B, (s + 1) * B), di.view(s * B, (s + 1) * B), dj.view(s * B, (s + 1) * B), 0.01, 0.05)
+    c = [dev.array(x) for x in (P, Q, b)]
+    dev.prepare_batches(0, U, I, du, di, dj, 2)
+    for s in range(2):
+        dev.bpr_sgd_step_prepared(0, *c, 0.01, 0.05)
+    dev.synchronize()
+    for x, y in zip(a, c):
+        assert np.array_equal(x.numpy(), y.numpy())
+
+
 def test_bpr_step_is_reproducible(dev):
     rng = np.random.default_rng(3)
     U, I, d, B = 200, 100, 64, 50000

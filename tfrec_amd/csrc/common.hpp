@@ -110,7 +110,7 @@ int tfrec_sort_pairs(void *d_temp, size_t temp_bytes, const uint32_t *keys_in, u
 struct tfrec_triple_src {
     const int32_t *users, *pos, *neg;
     uint32_t n, B, U, I;
-    uint32_t inv_B;       // ceil(2^32 / B) (0 when n <= B: one batch, no batch numbers)
+    uint32_t inv_B;       // ceil(2^32 / B), any non-zero value when B = 1 (0 when n <= B: one batch, no batch numbers)
     int kb;
     uint32_t *pair;       // [2n] = uint2[n]: (i, j) range-checked
     uint32_t *flags;      // sticky error flags

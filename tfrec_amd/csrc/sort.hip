@@ -74,8 +74,10 @@ struct TripleSrcT {
         uint32_t k = 0, tau = t;
         if constexpr (MULTI) {
             // batch number t / B without a division: multiply by the rounded-up reciprocal, step back if that overshot
+            // (batches of one triple: the reciprocal 2^32 does not fit its 32 bits, and there is nothing to divide)
             k = __umulhi(t, a.inv_B);
             k -= (k * a.B > t) ? 1u : 0u;
+            k = a.B == 1u ? t : k;
             tau = t - k * a.B;
         }
         key_ = (k << a.kb) | (is_user ? c : a.U + c);

@@ -657,7 +657,8 @@ static int slot_prepare(tfrec_ctx *ctx, tfrec_batch_slot &sl, hipStream_t stream
     sl.pair = (uint2 *)take(8 * (size_t)n);
     void *sort_tmp = take(sort_bytes);
     // the first sort pass reads the index triples themselves (range check included) and leaves the checked items in pair
-    const uint32_t inv_B = K > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)B - 1) / (uint64_t)B) : 0u;
+    // ceil(2^32 / B), non-zero exactly when batch numbers are wanted (B = 1: the quotient does not fit, and is not used)
+    const uint32_t inv_B = K > 1 ? (B == 1 ? 0xffffffffu : (uint32_t)(((1ull << 32) + (uint64_t)B - 1) / (uint64_t)B)) : 0u;
     const tfrec_triple_src src{users, pos, neg, (uint32_t)n, (uint32_t)B, (uint32_t)U, (uint32_t)I, inv_B, kb,
                                reinterpret_cast<uint32_t *>(sl.pair), ctx->d_flags};
     TF_TRY(tfrec_sort_triples(sort_tmp, sort_bytes, src, sl.keys, sl.vals, total_bits, stream));
