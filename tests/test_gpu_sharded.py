@@ -73,15 +73,15 @@ def test_item_half_in_ranges_of_item_ids_equals_the_whole(K):
     assert cut.overlap_chunks == K and one.overlap_chunks == 1
     rng = np.random.default_rng(K)
     batches = []
-    for B, item_hi in ((200000, I), (300, I), (50000, 40), (1, I), (150000, I)):
+    for B, item_hi in ((200000, I), (300, I), (50000, 40), (0, I), (1, I), (150000, I)):       # (one batch is empty)
         u = rng.integers(0, U, B).astype(np.int32)
         i = np.minimum((rng.pareto(1.0, B) * 3).astype(np.int64), item_hi - 1).astype(np.int32)      # a few very hot items
         j = rng.integers(0, item_hi, B).astype(np.int32)
         batches.append([torch.from_numpy(x).to(cuda) for x in (u, i, j)])
     for tr in (one, cut):
-        for bt in batches[:4]:
+        for bt in batches[:5]:
             tr.step(*bt)
-        tr.prepare(0, *batches[4])
+        tr.prepare(0, *batches[5])
         tr.step_prepared(0, prepare_next=(1,) + tuple(batches[0]))
         tr.step_prepared(1)
     torch.cuda.synchronize()
