@@ -89,6 +89,16 @@ def other_paths(dev, P, Q, b, U, I, d, B, gen, cuda, steps=10, epoch_pipeline=Tr
     out["apr_adagrad_step"] = {"triples_per_s": B / (ms * 1e-3), "ms_per_step": ms, "batch": B,
                                "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                             "algorithmic_bytes_per_triple": 84 * d + 68}}
+    # the reference's own APR batch size (conf/APR.ini:4: 128 triples per step)
+    small = 128
+    for k in range(220):
+        if k == 20:
+            e0.record()
+        o = (k % 1000) * small
+        dev.apr_adagrad_step(Pa, Qa, ba, acc[0], acc[1], acc[2], dl[0], dl[1], dl[2], users[o:o + small], pos[o:o + small],
+                             neg[o:o + small], 0.05, 0.0, 1.0, 0.5)
+    e1.record(); torch.cuda.synchronize()
+    out["apr_reference_batch_128"] = {"us_per_step": e0.elapsed_time(e1) * 1e3 / 200, "triples_per_s": 200 * small / (e0.elapsed_time(e1) * 1e-3)}
     del acc, dl, Pa, Qa, ba
     Cn = 32
     cand = torch.randint(0, I, (B, Cn), device=cuda, generator=gen, dtype=torch.int32)

@@ -286,9 +286,9 @@ __device__ __forceinline__ float clip_softplus_neg(float r) { return softplus_ne
 
 // phase 1, user side: s_t and delta_P rows (P is not modified in this phase, so the item side
 // gathers P[u] straight from the table)
-template <int LPR_, int NCH_, int VEC_, bool FULL_>
+template <int LPR_, int NCH_, int VEC_, bool FULL_, bool SHORT = false>
 struct AprUser1Pol {
-    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_, DEPTH = 4 };
+    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_, DEPTH = 4, SHORT_TILES = SHORT };
     using RowT = Row<LPR_, NCH_, VEC_>;
     using DM = RowDims<LPR_, NCH_, VEC_, FULL_>;
     using Loss = LossAcc<0>;
@@ -336,9 +336,9 @@ struct AprUser1Pol {
 // phase 1, item side: delta_Q rows, raw bias gradient into db, and sum of its squares.
 // GRAD = true leaves the raw gradient sums in gQ / gb instead (they are then summed over the GPUs
 // before they are normalised).
-template <int LPR_, int NCH_, int VEC_, bool FULL_, bool GRAD = false>
+template <int LPR_, int NCH_, int VEC_, bool FULL_, bool GRAD = false, bool SHORT = false>
 struct AprItem1Pol {
-    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_, DEPTH = 8 };
+    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_, DEPTH = 8, SHORT_TILES = SHORT };
     using RowT = Row<LPR_, NCH_, VEC_>;
     using DM = RowDims<LPR_, NCH_, VEC_, FULL_>;
     using Loss = LossAcc<0>;
@@ -379,9 +379,9 @@ struct AprItem1Pol {
 };
 
 // phase 2, user side
-template <int LPR_, int NCH_, int VEC_, bool FULL_, bool LOSS>
+template <int LPR_, int NCH_, int VEC_, bool FULL_, bool LOSS, bool SHORT = false>
 struct AprUser2Pol {
-    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_, DEPTH = 2 };
+    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_, DEPTH = 2, SHORT_TILES = SHORT };
     using RowT = Row<LPR_, NCH_, VEC_>;
     using DM = RowDims<LPR_, NCH_, VEC_, FULL_>;
     using Loss = LossAcc<LOSS ? 3 : 0>;
@@ -456,9 +456,9 @@ struct AprUser2Pol {
 
 // phase 2, item side.  GRAD = true leaves the gradient sums (mean-square term included) in gQ / gb
 // and touches neither the tables nor the accumulators.
-template <int LPR_, int NCH_, int VEC_, bool FULL_, bool GRAD = false>
+template <int LPR_, int NCH_, int VEC_, bool FULL_, bool GRAD = false, bool SHORT = false>
 struct AprItem2Pol {
-    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_, DEPTH = 8 };
+    enum { LPR = LPR_, NCH = NCH_, VEC = VEC_, DEPTH = 8, SHORT_TILES = SHORT };
     using RowT = Row<LPR_, NCH_, VEC_>;
     using DM = RowDims<LPR_, NCH_, VEC_, FULL_>;
     using Loss = LossAcc<0>;
@@ -682,6 +682,18 @@ struct StepWs {
 // batches up to this many triples run the BPR row passes on short tiles
 static constexpr int64_t SHORT_TILES_MAX_B = TF_SHORT_TILES_MAX_B;
 
+// dispatch_cfg plus the choice between long and short tiles: f is called with <LPR, NCH, VEC, FULL, SHORT>
+template <class F>
+static int dispatch_cfg_tiles(const RowCfg &cfg, bool short_tiles, F &&f)
+{
+    return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC, bool FULL>() -> int {
+        // (a lane group of 64 has no shorter tile than the regular one)
+        if constexpr (short_tile_ch(LPR) < tile_ch(LPR))
+            if (short_tiles) return f.template operator()<LPR, NCH, VEC, FULL, true>();
+        return f.template operator()<LPR, NCH, VEC, FULL, false>();
+    });
+}
+
 // (sized for the short tiles of small batches where those may be used: more tiles, more partial records)
 static size_t step_ws_bytes(int64_t B, int d, const RowCfg &c)
 {
@@ -886,11 +898,8 @@ static int bpr_passes(tfrec_ctx *ctx, const tfrec_batch_slot &sl, float *d_P, fl
                         "item_tile", "item_fixup");
     };
     auto layout = [&]<bool VER>() -> int {
-        return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC, bool FULL>() -> int {
-            // (a lane group of 64 has no shorter tile than the regular one)
-            if constexpr (short_tile_ch(LPR) < tile_ch(LPR))
-                if (short_tiles) return passes.template operator()<LPR, NCH, VEC, FULL, VER, true>();
-            return passes.template operator()<LPR, NCH, VEC, FULL, VER, false>();
+        return dispatch_cfg_tiles(cfg, short_tiles, [&]<int LPR, int NCH, int VEC, bool FULL, bool SHORT>() -> int {
+            return passes.template operator()<LPR, NCH, VEC, FULL, VER, SHORT>();
         });
     };
     if (!ut) return layout.template operator()<false>();
@@ -1322,7 +1331,8 @@ extern "C" int tfrec_apr_adagrad_step(tfrec_ctx *ctx, float *d_P, float *d_Q, fl
     TF_TRY(slot_prepare(ctx, sl, ctx->stream, d_users, d_pos, d_neg, B, U, I));
     tfrec_mark(ctx, "index");
     StepWs w;
-    TF_TRY(step_ws_carve(ctx, B, d, cfg, &w));
+    const bool short_tiles = B <= SHORT_TILES_MAX_B;
+    TF_TRY(step_ws_carve(ctx, B, d, cfg, &w, true, short_tiles));
 
     AprParams a{};
     a.P = d_P; a.Q = d_Q; a.b = d_b; a.accP = d_accP; a.accQ = d_accQ; a.accb = d_accb;
@@ -1331,11 +1341,11 @@ extern "C" int tfrec_apr_adagrad_step(tfrec_ctx *ctx, float *d_P, float *d_Q, fl
     a.U = (uint32_t)U; a.d = d; a.nchunk = d / cfg.vec;
     a.lr = lr; a.reg_coef = (float)(4.0 * (double)reg / ((double)B * (double)d)); a.reg_adv = reg_adv; a.eps = eps;
     const bool want_loss = d_loss != nullptr;
-    return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC, bool FULL>() -> int {
+    return dispatch_cfg_tiles(cfg, short_tiles, [&]<int LPR, int NCH, int VEC, bool FULL, bool SHORT>() -> int {
         // phase 1: deltas
-        TF_TRY(run_pass(ctx, AprUser1Pol<LPR, NCH, VEC, FULL>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, false,
+        TF_TRY(run_pass(ctx, AprUser1Pol<LPR, NCH, VEC, FULL, SHORT>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, false,
                         "delta_user_tile", "delta_user_fixup"));
-        TF_TRY(run_pass(ctx, AprItem1Pol<LPR, NCH, VEC, FULL>{a}, w, sl.keys, sl.vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false,
+        TF_TRY(run_pass(ctx, AprItem1Pol<LPR, NCH, VEC, FULL, false, SHORT>{a}, w, sl.keys, sl.vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false,
                         "delta_item_tile", "delta_item_fixup"));
         const int nb = (int)((2 * B + 255) / 256 < 512 ? (2 * B + 255) / 256 : 512);
         apr_bias_norm_kernel<<<nb, 256, 0, ctx->stream>>>(sl.keys, B, 2 * B, (uint32_t)U, d_db, w.loss_part);
@@ -1347,15 +1357,15 @@ extern "C" int tfrec_apr_adagrad_step(tfrec_ctx *ctx, float *d_P, float *d_Q, fl
         tfrec_mark(ctx, "delta_bias_norm");
         // phase 2: Adagrad step at (Theta, delta)
         if (want_loss) {
-            TF_TRY(run_pass(ctx, AprUser2Pol<LPR, NCH, VEC, FULL, true>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, true,
+            TF_TRY(run_pass(ctx, AprUser2Pol<LPR, NCH, VEC, FULL, true, SHORT>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, true,
                             "user_tile", "user_fixup"));
             loss_finalize_kernel<3><<<1, 256, 0, ctx->stream>>>(w.loss_part, w.blocks_u, w.scalars + 4);
             TF_HIP(hipGetLastError());
         } else {
-            TF_TRY(run_pass(ctx, AprUser2Pol<LPR, NCH, VEC, FULL, false>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, false,
+            TF_TRY(run_pass(ctx, AprUser2Pol<LPR, NCH, VEC, FULL, false, SHORT>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, false,
                             "user_tile", "user_fixup"));
         }
-        TF_TRY(run_pass(ctx, AprItem2Pol<LPR, NCH, VEC, FULL>{a}, w, sl.keys, sl.vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false, "item_tile",
+        TF_TRY(run_pass(ctx, AprItem2Pol<LPR, NCH, VEC, FULL, false, SHORT>{a}, w, sl.keys, sl.vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false, "item_tile",
                         "item_fixup"));
         if (want_loss) {
             // the third number is a mean over B*d entries
@@ -1426,7 +1436,7 @@ static int apr_common(tfrec_ctx *ctx, AprParams *a, RowCfg *cfg, StepWs *w, cons
                       std::initializer_list<const void *> tables)
 {
     TF_REQUIRE(pick_cfg(d, all_aligned16(tables), cfg), TFREC_EUNSUP, "factor size d=%d is not supported (max 256)", d);
-    TF_TRY(step_ws_carve(ctx, B, d, *cfg, w));
+    TF_TRY(step_ws_carve(ctx, B, d, *cfg, w, true, B <= SHORT_TILES_MAX_B));
     a->stage = w->stage; a->sbuf = w->sbuf; a->pair = sl.pair;
     a->d = d; a->nchunk = d / cfg->vec;
     return TFREC_OK;
@@ -1455,10 +1465,10 @@ extern "C" int tfrec_apr_dense_delta_grads(tfrec_ctx *ctx, const float *d_P, con
     a.P = const_cast<float *>(d_P); a.Q = const_cast<float *>(d_Q); a.b = const_cast<float *>(d_b);
     a.dP = d_dP; a.gQ = d_G; a.gb = d_G + (size_t)I * d;
     a.users = d_users; a.U = (uint32_t)U; a.eps = eps;
-    TF_TRY(dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC, bool FULL>() -> int {
-        TF_TRY(run_pass(ctx, AprUser1Pol<LPR, NCH, VEC, FULL>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, false,
+    TF_TRY(dispatch_cfg_tiles(cfg, B <= SHORT_TILES_MAX_B, [&]<int LPR, int NCH, int VEC, bool FULL, bool SHORT>() -> int {
+        TF_TRY(run_pass(ctx, AprUser1Pol<LPR, NCH, VEC, FULL, SHORT>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, false,
                         "delta_user_tile", "delta_user_fixup"));
-        return run_pass(ctx, AprItem1Pol<LPR, NCH, VEC, FULL, true>{a}, w, sl.keys, sl.vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false,
+        return run_pass(ctx, AprItem1Pol<LPR, NCH, VEC, FULL, true, SHORT>{a}, w, sl.keys, sl.vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false,
                         "delta_item_tile", "delta_item_fixup");
     }));
     sl.apr_pending = 1;
@@ -1516,17 +1526,17 @@ extern "C" int tfrec_apr_dense_adagrad_grads(tfrec_ctx *ctx, float *d_P, const f
     a.U = (uint32_t)U; a.lr = lr; a.reg_adv = reg_adv;
     a.reg_coef = (float)(4.0 * (double)reg / ((double)B_total * (double)d));
     const bool want_loss = d_loss != nullptr;
-    return dispatch_cfg(cfg, [&]<int LPR, int NCH, int VEC, bool FULL>() -> int {
+    return dispatch_cfg_tiles(cfg, B <= SHORT_TILES_MAX_B, [&]<int LPR, int NCH, int VEC, bool FULL, bool SHORT>() -> int {
         if (want_loss) {
-            TF_TRY(run_pass(ctx, AprUser2Pol<LPR, NCH, VEC, FULL, true>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, true,
+            TF_TRY(run_pass(ctx, AprUser2Pol<LPR, NCH, VEC, FULL, true, SHORT>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, true,
                             "user_tile", "user_fixup"));
             loss_finalize_kernel<3><<<1, 256, 0, ctx->stream>>>(w.loss_part, w.blocks_u, w.scalars + 4);
             TF_HIP(hipGetLastError());
         } else {
-            TF_TRY(run_pass(ctx, AprUser2Pol<LPR, NCH, VEC, FULL, false>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, false,
+            TF_TRY(run_pass(ctx, AprUser2Pol<LPR, NCH, VEC, FULL, false, SHORT>{a}, w, sl.keys, sl.vals, 0, B, w.n_tiles_u, w.blocks_u, false,
                             "user_tile", "user_fixup"));
         }
-        TF_TRY(run_pass(ctx, AprItem2Pol<LPR, NCH, VEC, FULL, true>{a}, w, sl.keys, sl.vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false,
+        TF_TRY(run_pass(ctx, AprItem2Pol<LPR, NCH, VEC, FULL, true, SHORT>{a}, w, sl.keys, sl.vals, B, 2 * B, w.n_tiles_i, w.blocks_i, false,
                         "item_tile", "item_fixup"));
         if (want_loss) {
             // this GPU's share of the three sums; the third is divided by the entry count of the whole batch
