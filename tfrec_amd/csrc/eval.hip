@@ -1104,8 +1104,11 @@ struct ScorePlan {
     int CAP, D, TI, splits;
     bool bf16, direct;
     int64_t n_items, split_items, chunk;
-    size_t q_bytes, list_bytes, part_bytes, total;
+    size_t q_bytes, list_bytes, part_bytes, part2_bytes, total;
 };
+
+// lists of k one merge launch takes per user (its sort buffer holds 2048 candidates)
+static inline int merge_group(int k) { return 2048 / k; }
 
 static int plan_score(const float *d_Q, int d, int64_t item_lo, int64_t item_hi, int64_t n, int k, int score_mode, ScorePlan *p)
 {
@@ -1130,8 +1133,14 @@ static int plan_score(const float *d_Q, int d, int64_t item_lo, int64_t item_hi,
         const int64_t maxs = (p->n_items + 4095) / 4096;
         splits = (int)(want < maxs ? want : maxs);
         if (splits < 1) splits = 1;
-        if (splits > 16) splits = 16;              // beyond that the merge of the partial lists costs more than the scan gains
-        if ((int64_t)splits * k > 2048) splits = 2048 / k;
+        // beyond 16 the merge of the partial lists costs more than the scan gains -- except for a handful of users
+        // (a few workgroups' worth: a serving call), where the scan of one workgroup IS the latency of the call: there
+        // the item range goes to up to 128 workgroups and the partial lists are merged in two levels
+        const bool handful = user_blocks_all <= 4;
+        const int cap = handful ? (int)(128 / user_blocks_all) : 16;
+        if (splits > cap) splits = cap;
+        const int g1 = merge_group(k);
+        if ((int64_t)splits * k > 2048) splits = handful ? (splits < g1 * g1 ? splits : g1 * g1) : g1;
     }
     p->split_items = p->n_items > 0 ? ((p->n_items + splits - 1) / splits + p->TI - 1) / p->TI * p->TI : p->TI;
     p->splits = p->n_items > 0 ? (int)((p->n_items + p->split_items - 1) / p->split_items) : 1;
@@ -1139,7 +1148,9 @@ static int plan_score(const float *d_Q, int d, int64_t item_lo, int64_t item_hi,
     p->q_bytes = p->direct ? 0 : tf_align((size_t)p->n_items * p->D * (p->bf16 ? 2 : 4));
     p->list_bytes = tf_align(sizeof(uint64_t) * (size_t)p->splits * nc * p->CAP);
     p->part_bytes = p->splits > 1 ? tf_align((size_t)p->splits * nc * k * 4) : 0;
-    p->total = p->q_bytes + p->list_bytes + 2 * p->part_bytes + 4096;
+    const int64_t groups = (p->splits + merge_group(k) - 1) / merge_group(k);
+    p->part2_bytes = (int64_t)p->splits * k > 2048 ? tf_align((size_t)groups * nc * k * 4) : 0;
+    p->total = p->q_bytes + p->list_bytes + 2 * p->part_bytes + 2 * p->part2_bytes + 4096;
     return TFREC_OK;
 }
 
@@ -1173,7 +1184,9 @@ static int score_topk_impl(tfrec_ctx *ctx, const float *d_P, const float *d_Q, c
     uint64_t *lists = (uint64_t *)tfrec_ws_take(ctx, pl.list_bytes);
     int32_t *part_ids = splits > 1 ? (int32_t *)tfrec_ws_take(ctx, pl.part_bytes) : nullptr;
     float *part_sc = splits > 1 ? (float *)tfrec_ws_take(ctx, pl.part_bytes) : nullptr;
-    TF_REQUIRE(lists != nullptr, TFREC_ENOMEM, "internal: workspace carve failed");
+    int32_t *part2_ids = pl.part2_bytes ? (int32_t *)tfrec_ws_take(ctx, pl.part2_bytes) : nullptr;
+    float *part2_sc = pl.part2_bytes ? (float *)tfrec_ws_take(ctx, pl.part2_bytes) : nullptr;
+    TF_REQUIRE(lists != nullptr && (!pl.part2_bytes || part2_sc != nullptr), TFREC_ENOMEM, "internal: workspace carve failed");
 
     if (!direct) {
         const int64_t total = n_items * D;
@@ -1208,7 +1221,18 @@ static int score_topk_impl(tfrec_ctx *ctx, const float *d_P, const float *d_Q, c
         const int user_blocks = (int)((nn + ub - 1) / ub);
         if (CAP == 256) TF_TRY(launch_score_cap<256>(ctx, a, D, score_mode, user_blocks, splits));
         else TF_TRY(launch_score_cap<512>(ctx, a, D, score_mode, user_blocks, splits));
-        if (splits > 1) TF_TRY(merge_lists(ctx, part_ids, part_sc, splits, nn, k, d_out_ids + (size_t)u0 * k, d_out_scores + (size_t)u0 * k));
+        if (splits > 1 && !pl.part2_bytes) {
+            TF_TRY(merge_lists(ctx, part_ids, part_sc, splits, nn, k, d_out_ids + (size_t)u0 * k, d_out_scores + (size_t)u0 * k));
+        } else if (splits > 1) {
+            // two levels: groups of lists first (the total order makes the merge of merged lists the merge of all)
+            const int g1 = merge_group(k), groups = (splits + g1 - 1) / g1;
+            for (int g = 0; g < groups; ++g) {
+                const int cnt = splits - g * g1 < g1 ? splits - g * g1 : g1;
+                const size_t src = (size_t)g * g1 * nn * k, dst = (size_t)g * nn * k;
+                TF_TRY(merge_lists(ctx, part_ids + src, part_sc + src, cnt, nn, k, part2_ids + dst, part2_sc + dst));
+            }
+            TF_TRY(merge_lists(ctx, part2_ids, part2_sc, groups, nn, k, d_out_ids + (size_t)u0 * k, d_out_scores + (size_t)u0 * k));
+        }
     }
     return TFREC_OK;
 }
