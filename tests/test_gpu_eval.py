@@ -189,6 +189,29 @@ def test_few_users_many_items_uses_item_splits(dev, oracle):
         assert np.array_equal(ids.numpy()[u], oracle.topk_row(row, k))
 
 
+@pytest.mark.parametrize("k", [100, 240])
+def test_a_handful_of_users_merges_item_splits_in_two_levels(dev, oracle, k):
+    """Five users against 300,000 items: the item range goes to many more workgroups than one merge launch takes
+    lists (2048 candidates per user), so the partial lists are merged in two levels; same lists as one pass."""
+    rng = np.random.default_rng(k)
+    U, I, d = 5, 300000, 32
+    P = rng.normal(size=(U, d)).astype(np.float32); Q = rng.normal(size=(I, d)).astype(np.float32)
+    b = rng.normal(size=I).astype(np.float32)
+    deg = 40
+    indptr = np.arange(0, deg * (U + 1), deg, dtype=np.int64)
+    rows = [oracle.score_row(P[u], Q, b, mode=1) for u in range(U)]
+    # mask each user's best items, so that masking across splits matters
+    indices = np.concatenate([np.sort(np.argsort(-rows[u], kind="stable")[:deg]) for u in range(U)]).astype(np.int32)
+    ids, sc = dev.score_topk(dev.array(P), dev.array(Q), dev.array(b), dev.array(np.arange(U, dtype=np.int32)), k,
+                             train=dcsr(dev, indptr, indices))
+    dev.synchronize()
+    for u in range(U):
+        row = rows[u].copy()
+        row[indices[indptr[u]:indptr[u + 1]]] = -np.inf
+        assert np.array_equal(ids.numpy()[u], oracle.topk_row(row, k))
+        assert np.array_equal(sc.numpy()[u], row[ids.numpy()[u]])
+
+
 def test_bf16_scoring(dev, oracle):
     rng = np.random.default_rng(8)
     U, I, d, k = 200, 5000, 128, 100
