@@ -131,11 +131,13 @@ def main():
             "Per-step figure = sum over all launches in the pass / steps.", "",
             "| kernel | launches/step | fetched MB/step (guide x2) | fetched MB/step (calibrated) | written MB/step |", "|---|---|---|---|---|"]
     tot_guide = tot_cal = tot_w = 0.0
+    moved = {}            # calibrated MB per step, by kernel
     for k in sorted(set(f) | set(w)):
         fk = sum(f.get(k, [0])) * 1024 / 1e6 / steps
         wk = sum(w.get(k, [0])) * 1024 / 1e6 / steps
         cal = fk * (1.3333 if k.startswith(GATHER_KERNELS) else 2.0)
         tot_guide += 2 * fk; tot_cal += cal; tot_w += wk
+        moved[k] = cal + wk
         out.append("| `%s` | %.1f | %.0f | %.0f | %.0f |" % (k, len(f.get(k, [])) / steps, 2 * fk, cal, wk))
     B = line["config"]["batch_per_gpu"]
     alg = B * rf["algorithmic_bytes_per_triple"] / 1e6
@@ -143,6 +145,18 @@ def main():
                 tot_guide, tot_cal, tot_w, tot_cal + tot_w),
             "Algorithmic bytes per step: %d x %d = %.0f MB, so measured traffic is %.2fx algorithmic (calibrated; %.2fx with the guide's x2)." % (
                 B, rf["algorithmic_bytes_per_triple"], alg, (tot_cal + tot_w) / alg, (tot_guide + tot_w) / alg), ""]
+    # measured traffic of a phase over its duration in the un-pipelined step, against the streaming-copy rate of the chip
+    ph = rf["phases_ms"]
+    groups = {"index": ("sort_",), "user_tile": ("seg_tile_kernel<BprUserPol>",), "user_fixup": ("seg_fixup_kernel<BprUserPol>",),
+              "item_tile": ("seg_tile_kernel<BprItemPol>",), "item_fixup": ("seg_fixup_kernel<BprItemPol>",)}
+    out += ["Rate of each phase = its measured traffic / its duration in an un-pipelined step (HIP events of the bench line), against the",
+            "6.29 TB/s a streaming copy reaches on this chip:", "", "| phase | MB/step | ms | TB/s | of 6.29 TB/s |", "|---|---|---|---|---|"]
+    for name, keys in groups.items():
+        mb = sum(v for k, v in moved.items() if k.startswith(keys))
+        if name in ph and ph[name] > 0:
+            tbs = mb / 1e6 / (ph[name] * 1e-3)
+            out.append("| %s | %.0f | %.3f | %.2f | %.2f |" % (name, mb, ph[name], tbs, tbs / 6.29))
+    out.append("")
     if len(sys.argv) >= 9:
         out += eval_section(sys.argv[6], sys.argv[7], sys.argv[8])
     json.dump({"workload_batch": B, "factors": line["config"]["factors"],
