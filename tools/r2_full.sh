@@ -16,7 +16,7 @@ e = o["eval"]
 for shape in (e, e["c5"]):
     for case in ("independent", "popularity_biased"):
         print(shape["shape"][:8], case, {m: (round(shape[case][m]["ms"], 2), round(shape[case][m]["roofline"]["frac"], 3)) for m in ("f32", "bf16")})
-print({k: (round(v.get("ms_per_step", v.get("ms", v.get("ms_per_epoch"))), 3), round(v.get("roofline", {}).get("frac", 0), 3)) for k, v in o["other_paths"].items()})
+print({k: (round(v.get("ms_per_step", v.get("ms", v.get("ms_per_epoch", v.get("us_per_step", 0) / 1e3))), 3), round(v.get("roofline", {}).get("frac", 0), 3)) for k, v in o["other_paths"].items()})
 print(o["cpu_baseline"]["value"], o["cpu_baseline"]["cores"], o["eval"]["cpu_baseline"]["value"])
 t = json.loads(open("gpurun_out/r2_bench_2r.json").read().strip().splitlines()[-1])
 print("2 ranks (one GPU, gloo):", t["n_gpus"], round(t["ms_per_step"], 2), "ms")
