@@ -191,6 +191,103 @@ def test_two_ranks_dense_mode_match_one_rank(tmp_path):
     dev.close()
 
 
+def _one_rank_rccl_worker(rank, world, port, out_dir):
+    """A process group of ONE rank over RCCL (backend "nccl") on the test GPU: every collective of the trainers and
+    the evaluator runs through RCCL (trivially), on the streams and tensors it meets in a many-GPU run."""
+    import os
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from tfrec_amd.sharded import ShardedBprTrainer, ShardedEvaluator, make_device
+    dev = make_device(0)
+    cuda = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=cuda)
+    U, I, d, B, k = 3000, 1100, 64, 25000, 20
+    rng = np.random.default_rng(4)
+    batches = [[torch.from_numpy(rng.integers(0, n, B).astype(np.int32)).to(cuda) for n in (U, I, I)] for _ in range(3)]
+    out = {}
+    for mode, chunks in (("dense", 3), ("sharded", None)):
+        tr = ShardedBprTrainer(dev, U, I, d, 0.01, 0.05, seed=9, item_mode=mode, overlap_chunks=chunks)
+        assert tr._coll and tr.world == 1
+        if mode == "dense":
+            assert tr.overlap_chunks == 3
+            tr.prepare(0, *batches[0])
+            for s in range(3):
+                tr.step_prepared(s & 1, prepare_next=(((s + 1) & 1,) + tuple(batches[s + 1])) if s + 1 < 3 else None)
+        else:
+            for plan in tr.plan_steps(batches):
+                tr.step_planned(plan)
+        P, Q, b = tr.gather_full()
+        deg = 5
+        tptr = torch.arange(0, deg * (U + 1), deg, dtype=torch.int64, device=cuda)
+        tidx = torch.from_numpy(np.sort(np.random.default_rng(5).integers(0, I, (U, deg)), axis=1).astype(np.int32).ravel()).to(cuda)
+        eptr = torch.arange(0, 2 * (U + 1), 2, dtype=torch.int64, device=cuda)
+        eidx = torch.from_numpy(np.sort(np.random.default_rng(6).integers(0, I, (U, 2)), axis=1).astype(np.int32).ravel()).to(cuda)
+        users = torch.arange(0, U, 4, dtype=torch.int32, device=cuda)
+        m = ShardedEvaluator(dev, tr, (tptr, tidx), (eptr, eidx), users, top_k=k, chunk_users=200).evaluate()
+        torch.cuda.synchronize()
+        out.update({mode + "_P": P.cpu().numpy(), mode + "_Q": Q.cpu().numpy(), mode + "_b": b.cpu().numpy(), mode + "_m": m.cpu().numpy()})
+    # the APR step (two all-reduces of the item gradient table per step, the loss summed over the ranks)
+    from test_gpu_sharded import _apr_problem, APR_HP
+    from tfrec_amd.sharded import ShardedAprTrainer
+    params, abatches = _apr_problem(U, I, d, 8000, 2, 5)
+    apr = ShardedAprTrainer(dev, U, I, d, APR_HP["lr"], APR_HP["reg"], APR_HP["reg_adv"], APR_HP["eps"], params=params)
+    loss = torch.zeros(3, dtype=torch.float64, device=cuda)
+    for u, i, j in abatches:
+        apr.step(*(torch.from_numpy(x).to(cuda) for x in (u, i, j)), loss=loss)
+    aP, aQ, ab = apr.gather_full()
+    torch.cuda.synchronize()
+    out.update({"apr_P": aP.cpu().numpy(), "apr_Q": aQ.cpu().numpy(), "apr_b": ab.cpu().numpy(), "apr_loss": loss.cpu().numpy()})
+    np.savez(os.path.join(out_dir, "rccl1.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+    dev.close()
+
+
+def test_one_rank_process_group_over_rccl(tmp_path):
+    """Both layouts, the overlapped all-reduce and the evaluator with RCCL as the backend (one rank): the results of
+    the plain single-GPU entry points."""
+    import socket
+    import torch.multiprocessing as mp
+    from tfrec_amd.device import Device
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_one_rank_rccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    r = np.load(str(tmp_path / "rccl1.npz"))
+    dev = Device(0)
+    U, I, d, B, k = 3000, 1100, 64, 25000, 20
+    P = dev.uniform((U, d), -0.05, 0.05, 9 * 2 + 1)
+    Q = dev.uniform((I, d), -0.05, 0.05, 9 * 2 + 2)
+    b = dev.zeros(I, np.float32)
+    rng = np.random.default_rng(4)
+    for _ in range(3):
+        u, i, j = [dev.array(rng.integers(0, n, B).astype(np.int32), np.int32) for n in (U, I, I)]
+        dev.bpr_sgd_step(P, Q, b, u, i, j, 0.01, 0.05)
+    dev.synchronize()
+    for mode in ("dense", "sharded"):
+        np.testing.assert_allclose(r[mode + "_P"], P.numpy(), rtol=1e-5, atol=1e-7, err_msg=mode)
+        np.testing.assert_allclose(r[mode + "_Q"], Q.numpy(), rtol=1e-5, atol=1e-7, err_msg=mode)
+        np.testing.assert_allclose(r[mode + "_b"], b.numpy(), rtol=1e-5, atol=1e-7, err_msg=mode)
+    np.testing.assert_allclose(r["dense_m"], r["sharded_m"], rtol=1e-5, atol=1e-7)
+    assert r["dense_m"].shape == (5, k) and np.isfinite(r["dense_m"]).all()
+    # APR: the single-GPU entry point on the same batches
+    params, abatches = _apr_problem(U, I, d, 8000, 2, 5)
+    aP, aQ, ab = (dev.array(x.copy()) for x in params)
+    acc = [dev.full(x.shape, 0.1) for x in params]
+    dl = [dev.zeros(x.shape, np.float32) for x in params]
+    ref_loss = dev.zeros(3, np.float64)
+    for u, i, j in abatches:
+        dev.apr_adagrad_step(aP, aQ, ab, *acc, *dl, dev.array(u, np.int32), dev.array(i, np.int32), dev.array(j, np.int32),
+                             APR_HP["lr"], APR_HP["reg"], APR_HP["reg_adv"], APR_HP["eps"], loss=ref_loss)
+    dev.synchronize()
+    for got, want in ((r["apr_P"], aP), (r["apr_Q"], aQ), (r["apr_b"], ab)):
+        np.testing.assert_allclose(got, want.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(r["apr_loss"], ref_loss.numpy(), rtol=1e-6)
+    dev.close()
+
+
 @pytest.mark.parametrize("item_mode", ["dense", "sharded"])
 def test_sharded_epoch_sampler_on_the_gpu(oracle, item_mode):
     """ShardedEpochSampler with the HIP backend (one rank): DNS pools, picks and one collective epoch
