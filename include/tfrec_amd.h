@@ -145,7 +145,8 @@ int tfrec_bpr_sgd_step(tfrec_ctx *ctx, float *d_P, float *d_Q, float *d_b,
  * does not fit (about 40,000 triples at d=64, 23,000 at d=128, 12,000 at d=256) is rejected with TFREC_EUNSUP
  * before anything is launched.  All calls on one GPU share that GPU's array: calls that overlap there (two
  * contexts or streams on one device) race; calls in stream order do not, and nothing needs clearing between
- * them.  Phase timing is off during the call. */
+ * them.  Phase timing is off during the call.  The call borrows the context's workspace fields while it runs: the
+ * context must not be used from another host thread until it returns (contexts are not re-entrant anyway). */
 int tfrec_bpr_sgd_step_noalloc(tfrec_ctx *ctx, float *d_P, float *d_Q, float *d_b,
                                int64_t U, int64_t I, int d,
                                const int32_t *d_users, const int32_t *d_pos, const int32_t *d_neg, int64_t B,

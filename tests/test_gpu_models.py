@@ -252,3 +252,95 @@ def test_resume_from_a_checkpoint_continues_the_same_run(dev, tmp_path, sampler)
             assert np.array_equal(a, c)
         for a, c in zip(asecond.accumulators, awhole.accumulators):
             assert np.array_equal(a.numpy(), c.numpy())
+
+
+def test_bpr_large_batches_run_prepared_steps_on_the_versioned_table(dev, oracle, golden_ml100k):
+    """Batches of 65,536 triples and more take the path the benchmark times (versioned user table, index of the
+    next batch sorted ahead, tfrec_bpr_sgd_step_prepared_v; a short last batch included): two epochs on ML-100k equal
+    the oracle-driven schedule, and the user table is whole again (flattened) when the epoch is over."""
+    from tfrec_amd.evaluator import FoldOutEvaluator
+    from tfrec_amd.model import BPR
+    ds = ml100k(golden_ml100k)
+    ev = FoldOutEvaluator(ds.train_matrix, ds.test_matrix, top_k=50)
+    cfg = {"factors_num": 32, "lr": 0.0005, "reg": 0.05, "epochs": 2, "batch_size": 65536}
+    assert cfg["batch_size"] >= BPR.VERSIONED_FROM
+    BPR.logger = _Log()
+    np.random.seed(2018)
+    model = BPR(dev, cfg, ds, ev)
+    P, Q, b = model.mf.parameters()
+    model.train_model()
+    assert model._ut is not None                       # one table for the model's life, not one per epoch
+    rs = np.random.RandomState(2018)
+    user_pos = oracle.csr_to_user_dict(ds.train_matrix)
+    ws = oracle.Workspace(943, 1682, 32)
+    for ep in range(2):
+        u, i, j = oracle.bpr_epoch_triples(rs, user_pos, 1682)
+        for idx in oracle.batch_order(rs, len(u), 65536):
+            oracle.bpr_step(P, Q, b, u[idx], i[idx], j[idx], 0.0005, 0.05, ws=ws)
+    for a, c in zip(model.mf.parameters(), (P, Q, b)):
+        np.testing.assert_allclose(a, c, rtol=2e-4, atol=2e-6)
+
+
+def test_evaluator_options_top_k_score_dtype_metric_sum(dev, oracle, golden_ml100k):
+    """The optional evaluator settings of the configuration: ``top_k`` (the first k columns of a longer evaluation),
+    ``metric_sum = float64`` (device sums: the reference's float32 means to 5e-6), ``score_dtype = bf16`` (close to
+    the float32 ranking on a trained model), and the header line that names k."""
+    from tfrec_amd.evaluator import FoldOutEvaluator
+    g = golden_ml100k
+    ds = ml100k(g)
+
+    class _M:
+        def device_factors(self):
+            return dev, dP, dQ, db
+    dP, dQ, db = dev.array(g["P"]), dev.array(g["Q"]), dev.array(g["b"])
+    ref = FoldOutEvaluator(ds.train_matrix, ds.test_matrix).evaluate(_M()).reshape(5, 50)
+    assert FoldOutEvaluator(ds.train_matrix, ds.test_matrix).metrics_info() == "Precision@1:1:50, Recall@1:1:50, MAP@1:1:50, NDCG@1:1:50, MRR@1:1:50"
+    ev20 = FoldOutEvaluator.from_config({"top_k": 20}, ds.train_matrix, ds.test_matrix)
+    assert ev20.metrics_info().startswith("Precision@1:1:20")
+    np.testing.assert_allclose(ev20.evaluate(_M()).reshape(5, 20), ref[:, :20], rtol=1e-6, atol=1e-7)
+    f64 = FoldOutEvaluator.from_config({"metric_sum": "float64"}, ds.train_matrix, ds.test_matrix).evaluate(_M()).reshape(5, 50)
+    np.testing.assert_allclose(f64, ref, rtol=5e-6, atol=1e-7)
+    bf = FoldOutEvaluator.from_config({"score_dtype": "bf16", "metric_sum": "float64"}, ds.train_matrix, ds.test_matrix).evaluate(_M()).reshape(5, 50)
+    assert np.abs(bf - ref).max() < 0.02 and not np.array_equal(bf, ref)
+    with pytest.raises(ValueError):
+        FoldOutEvaluator.from_config({"score_dtype": "fp8"}, ds.train_matrix, ds.test_matrix)
+    with pytest.raises(ValueError):
+        FoldOutEvaluator.from_config({"metric_sum": "kahan"}, ds.train_matrix, ds.test_matrix)
+
+
+def _run_model(tmp, model, model_ini, tfrec_extra=""):
+    os.makedirs(tmp / "conf", exist_ok=True)
+    (tmp / "conf" / (model + ".ini")).write_text("[hyperparameters]\n" + model_ini)
+    ini = open(os.path.join(ROOT, "tfrec.ini")).read().replace("./dataset/", os.path.join(ROOT, "dataset") + "/")
+    ini = ini.replace("model=BPR", "model=" + model) + tfrec_extra
+    (tmp / "tfrec.ini").write_text(ini)
+    if not os.path.exists(os.path.join(ROOT, "dataset", "movielens-100k-train.txt")):
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "export_ml100k.py")])
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "run_model.py")], cwd=tmp, env=env, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    return out.stdout
+
+
+@pytest.mark.parametrize("model,ini,marker", [
+    ("BPR", "lr = 0.01\nreg = 0.05\nfactors_num = 20\nbatch_size = 512\nepochs = 2\nsampler = device\ntop_k = 20\nmetric_sum = float64\n", "epoch 1:\t"),
+    ("DNSBPR", "lr = 0.01\nreg = 0.05\nfactors_num = 20\nneg_num = 8\nbatch_size = 512\nepochs = 1\nsampler = device\ntop_k = 20\n"
+               "metric_sum = float64\nitem_mode = sharded\n", "epoch 0:\t"),
+])
+def test_run_model_on_two_ranks_gives_the_single_gpu_log(tmp_path, model, ini, marker):
+    """run_model.py with ``devices = 2`` starts two ranks of itself (both on the one test GPU, gloo between them), shards
+    the tables, and rank 0 logs: the metrics of the last epoch agree with the single-process run of the same
+    configuration (same draws, same global batches; sums associate differently across the ranks)."""
+    one = _run_model(tmp_path / "one", model, ini)
+    two = _run_model(tmp_path / "two", model, ini + "devices = 2\ndist_backend = 'gloo'\nsingle_device = True\n")
+    vals = []
+    for out in (one, two):
+        line = [ln for ln in out.splitlines() if marker in ln][-1]
+        vals.append(np.array([float(x) for x in line.split(marker)[1].split("\t")]))
+        assert vals[-1].shape == (100,)
+    assert vals[0][0] > 0.0
+    np.testing.assert_allclose(vals[1], vals[0], rtol=0, atol=0.01)
+    logs = os.listdir(tmp_path / "two" / "log" / "ml100k" / model)
+    assert len(logs) == 1                                  # rank 0 alone opens a log file
+    assert sum(1 for ln in two.splitlines() if marker in ln) == 1

@@ -81,6 +81,67 @@ def test_bpr_step_vs_oracle(dev, oracle, U, I, d, B, kind):
     assert np.array_equal(P1, P2) and np.array_equal(Q1, Q2) and np.array_equal(b1, b2)
 
 
+@pytest.mark.parametrize("path", ["versioned", "versioned_prepared", "dense_v", "dense_prepared_v", "dense_chunked"])
+def test_long_tile_steps_on_a_versioned_table_vs_oracle(dev, oracle, path):
+    """Batches of 300,000 triples (above the 131,072 at which the row passes switch to tiles of 64 occurrences and
+    the index to the radix passes), Zipf positives, two consecutive steps on a versioned user table, straight against
+    the CPU oracle: the plain versioned step, the step on batches sorted ahead, and the replicated-item-table
+    step (gradient table + axpy) unprepared, prepared and with its item half in three ranges of item ids."""
+    rng = np.random.default_rng(300000)
+    U, I, d, B = 20000, 5000, 64, 300000
+    lr, reg = 0.002, 0.05
+    P = rng.uniform(-0.3, 0.3, (U, d)).astype(np.float32)
+    Q = rng.uniform(-0.3, 0.3, (I, d)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, I).astype(np.float32)
+    batches = [(rng.integers(0, U, B).astype(np.int32), zipf_ids(rng, I, B).astype(np.int32), rng.integers(0, I, B).astype(np.int32))
+               for _ in range(2)]
+    Po, Qo, bo = P.copy(), Q.copy(), b.copy()
+    refs = []
+    for u, i, j in batches:
+        before = (Po.copy(), Qo.copy(), bo.copy())
+        oracle.bpr_step(Po, Qo, bo, u, i, j, lr, reg)
+        refs.append((before, (Po.copy(), Qo.copy(), bo.copy())))
+    dP, dQ, db = dev.array(P), dev.array(Q), dev.array(b)
+    ut = dev.user_table(dP)
+    dbt = [[dev.array(x) for x in bt] for bt in batches]
+    G = dev.zeros(I * d + I, np.float32)
+    events = None
+    if path == "dense_chunked":
+        import torch
+        events = [torch.cuda.Event() for _ in range(3)]
+        for e in events:
+            e.record()
+    if path in ("versioned_prepared", "dense_prepared_v"):
+        dev.prepare_batch(0, U, I, *dbt[0])
+    for s in range(2):
+        if path == "versioned":
+            dev.bpr_sgd_step_v(ut, dQ, db, *dbt[s], lr, reg)
+        elif path == "versioned_prepared":
+            if s == 0:
+                dev.prepare_batch(1, U, I, *dbt[1])
+            dev.bpr_sgd_step_prepared_v(s, ut, dQ, db, lr, reg)
+        else:
+            if path == "dense_v":
+                dev.bpr_dense_grad_step_v(ut, dQ, db, G, *dbt[s], lr, reg)
+            elif path == "dense_prepared_v":
+                if s == 0:
+                    dev.prepare_batch(1, U, I, *dbt[1])
+                dev.bpr_dense_grad_step_v(ut, dQ, db, G, None, None, None, lr, reg, slot=s)
+            else:
+                dev.bpr_dense_grad_step_chunked(ut, dQ, db, G, *dbt[s], lr, reg, [e.cuda_event for e in events])
+            dev.axpy(dQ, G.view(0, I * d), -lr, n=I * d)
+            dev.axpy(db, G.view(I * d, I * d + I), -lr, n=I)
+        # after every step: the flattened table and the item tables against the oracle's (increments compared: hot
+        # items collect tens of thousands of summed terms)
+        ut.flatten()
+        dev.synchronize()
+        (old, ref) = refs[s]
+        for new, r, o in zip((dP.numpy(), dQ.numpy(), db.numpy()), ref, old):
+            scale = max(np.abs(r - o).max(), 1e-3)
+            assert np.abs(new - r).max() <= 1e-5 * (s + 1) * scale + 2e-7 * np.abs(r).max(), (path, s)     # (step 2 starts from step 1's rounding)
+    ut.close()
+
+
 @pytest.mark.parametrize("B", [1, 2, 85, 86, 170, 171, 341, 342, 682, 683, 1365, 1366, 2730, 2731])
 def test_bpr_step_at_the_size_classes_of_the_single_workgroup_sort(dev, oracle, B):
     """3B pairs on either side of every size class of the one-workgroup index sort (256, 512, 1024, 2048, 4096, 8192
@@ -343,7 +404,23 @@ def test_full_size_step_10m_users_2m_items_d128(dev):
     _full_size_step_check(10_000_000, 2_000_000, 128, 1 << 21)
 
 
-def _full_size_step_check(U, I, d, B):
+def test_full_size_prepared_steps_on_a_versioned_table_against_float64_sums(dev):
+    """The path bench.py times for its headline number, at that size (1M users x 200k items, d=64, batches of 4M
+    triples: long tiles, three radix passes): a versioned user table, batches sorted ahead on the auxiliary stream,
+    tfrec_bpr_sgd_step_prepared_v, two consecutive batches (after the first, a quarter of the rows live in the
+    second buffer), flatten.  Every row against the float64 statement of the two steps."""
+    _full_size_step_check(1_000_000, 200_000, 64, 1 << 22, path="versioned_prepared")
+
+
+def test_full_size_versioned_steps_10m_users_2m_items_d128(dev):
+    """What bench.py times at the large configuration's table shape: tfrec_bpr_sgd_step_v, 4M triples per step,
+    10M users x 2M items, d=128, two consecutive steps, against float64 sums."""
+    _full_size_step_check(10_000_000, 2_000_000, 128, 1 << 22, path="versioned")
+
+
+def _full_size_step_check(U, I, d, B, path="plain"):
+    if path != "plain":
+        return _full_size_versioned_check(U, I, d, B, path)
     """A BPR step at full size (the bench workload: 1M users x 200k items, d=64, 4M triples, Zipf positives): every
     row of P, Q and b after one step against an independent float64 statement of model/BPR.py:36-48 built
     from torch gathers and sorted segment sums on the same device, plus two size-independent properties: a step with
@@ -396,6 +473,85 @@ def _full_size_step_check(U, I, d, B):
         d2.synchronize()
         moved = (b3.double() - b.double())
         assert abs(float(moved.sum())) <= 1e-5 * float(moved.abs().sum())
+        d2.close()
+
+
+def _float64_bpr_step(P, Q, b, u, i, j, lr, reg):
+    """model/BPR.py:36-48 in float64 on the device: (P, Q, b) float64 tensors after one step on float64 inputs."""
+    U, I = P.shape[0], Q.shape[0]
+    ul, il, jl = u.long(), i.long(), j.long()
+    p, qi, qj = P[ul], Q[il], Q[jl]
+    import torch
+    z = (p * (qi - qj)).sum(1) + (b[il] - b[jl]) + 1e-7
+    s = torch.sigmoid(-z)
+    gP = _sum_rows(U, [(ul, -s[:, None] * (qi - qj) + reg * p)])
+    gQ = _sum_rows(I, [(il, -s[:, None] * p + reg * qi), (jl, s[:, None] * p + reg * qj)])
+    gb = _sum_rows(I, [(il, -s + reg * b[il]), (jl, s + reg * b[jl])])
+    # what an item's bias update is summed from: -s per occurrence as a positive, +s per occurrence as a negative.  The
+    # two sides cancel, so the float32 sum is accurate relative to the sum of the magnitudes, not to the result.
+    b_terms = lr * _sum_rows(I, [(il, s), (jl, s)])
+    return P - lr * gP, Q - lr * gQ, b - lr * gb, b_terms
+
+
+def _full_size_versioned_check(U, I, d, B, path):
+    """Two consecutive steps on a versioned user table (``path``: "versioned" = tfrec_bpr_sgd_step_v, "versioned_prepared"
+    = batches sorted ahead with tfrec_batch_prepare_many + tfrec_bpr_sgd_step_prepared_v), then flatten.  Every row
+    of P, Q, b after the first step against a float64 step from the initial tables, and after both steps against a
+    float64 step from the device's own result of the first (the steps are reproducible bit for bit, so the run of two
+    steps passed through exactly that state, with the rows of the first batch's users in the second buffer); and
+    lr = 0 leaves every parameter bit for bit, in whichever buffer its row lives."""
+    import torch
+    from tfrec_amd.device import Device
+    cuda = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=cuda)
+    with torch.cuda.stream(stream):
+        d2 = Device(0, stream=stream.cuda_stream)
+        lr, reg = 0.01, 0.05
+        g = torch.Generator(device=cuda); g.manual_seed(199)
+        P = (torch.rand(U, d, device=cuda, generator=g) - 0.5) * 0.6
+        Q = (torch.rand(I, d, device=cuda, generator=g) - 0.5) * 0.6
+        b = torch.randn(I, device=cuda, generator=g) * 0.1
+        w = 1.0 / torch.arange(1, I + 1, device=cuda, dtype=torch.float64)
+        cdf = torch.cumsum(w, 0) / w.sum()
+        batches = []
+        for _ in range(2):
+            u = torch.randint(0, U, (B,), device=cuda, generator=g, dtype=torch.int32)
+            i = torch.searchsorted(cdf, torch.rand(B, device=cuda, generator=g, dtype=torch.float64)).clamp_(max=I - 1).to(torch.int32)
+            j = torch.randint(0, I, (B,), device=cuda, generator=g, dtype=torch.int32)
+            batches.append((u, i, j))
+
+        def run(lr_, n_steps):
+            P1, Q1, b1 = P.clone(), Q.clone(), b.clone()
+            ut = d2.user_table(P1)
+            if path == "versioned_prepared":
+                d2.prepare_batches(0, U, I, *batches[0], 1)
+                for s in range(n_steps):
+                    if s + 1 < n_steps:
+                        d2.prepare_batches((s + 1) & 1, U, I, *batches[s + 1], 1)
+                    d2.bpr_sgd_step_prepared_v(s & 1, ut, Q1, b1, lr_, reg)
+            else:
+                for bt in batches[:n_steps]:
+                    d2.bpr_sgd_step_v(ut, Q1, b1, *bt, lr_, reg)
+            ut.close()          # flattens
+            d2.synchronize()
+            return P1, Q1, b1
+
+        start = (P, Q, b)
+        for n_steps in (1, 2):
+            got = run(lr, n_steps)
+            *want, b_terms = _float64_bpr_step(*[x.double() for x in start], *batches[n_steps - 1], lr, reg)
+            for gt, wt in zip(got, want):
+                err = (gt.double() - wt).abs()
+                tol = ATOL + RTOL * wt.abs()
+                # hot items sum tens of thousands of float32 terms: their error is bounded relative to the row (and, for
+                # the bias, to the magnitude of the terms that cancel in it), not to the entry
+                row_scale = wt.abs().amax(dim=-1, keepdim=True) if wt.dim() == 2 else wt.abs() + b_terms
+                assert bool((err <= tol + RTOL * row_scale).all()), (n_steps, float((err - tol - RTOL * row_scale).max()))
+            del want, b_terms
+            start = got
+        del start, got
+        same = run(0.0, 2)
+        assert torch.equal(same[0], P) and torch.equal(same[1], Q) and torch.equal(same[2], b)
         d2.close()
 
 

@@ -16,7 +16,7 @@
 // table: step 2 updates P in place and stages a copy of the pre-step P[u] of every triple, which
 // is all that step 3 reads.  Versioned user table (tfrec_utable): step 2 writes the updated row
 // into the row's other buffer, step 3 reads the pre-step row where it still is, and the version
-// bytes of the batch's users are flipped at the end: no copies.
+// byte of a user is flipped as its new row is written: no copies.
 #include "seg_pass.hpp"
 
 #include <atomic>
@@ -50,8 +50,8 @@ struct BprParams {
     float *P, *Q, *b;
     // Versioned user table (tfrec_utable): row u lives in P2 when ver[u] is set, else in P.  A step reads the
     // current copy of a row and writes the updated row into the other buffer; the item pass, which needs the
-    // pre-step rows, still finds them where ver[] says; the version bytes of the batch's users are flipped when
-    // both passes are done.  Null in the plain layout.
+    // pre-step rows, finds them through the record every triple's user pass leaves (it carries the pre-step location);
+    // the user pass flips a user's version byte as it writes the user's new row.  Null in the plain layout.
     float *P2;
     uint8_t *ver;
     float *gQ, *gb;      // where the item pass leaves gradient sums when it does not apply them (may alias Q, b)
@@ -134,6 +134,12 @@ struct BprUserPol {
         const float nreg = (float)acc.cnt * a.reg, lr = a.lr;
         const RowT out = p.map2(acc.v, [=](float pv, float av) { return fmaf(-lr, fmaf(nreg, pv, -av), pv); });
         out.store(dst + off, gl, DM::nchunk(a.nchunk));
+        // The row now lives in the other buffer.  apply() runs once per distinct user of the batch (in the tile kernel
+        // for a run that lies inside one tile, in the fix-up kernel for a run cut by tile boundaries), after every
+        // entry() that looks this user's byte up has been staged: entries are staged by the tile that holds them,
+        // and a run that is applied in the tile kernel lies in that one tile.  The item pass does not read the
+        // bytes (the triples' records carry the pre-step location).
+        if constexpr (VER) if (gl == 0) a.ver[key & a.kmask] = v ? 0 : 1;
     }
 };
 
@@ -798,16 +804,6 @@ struct tfrec_utable {
     int d = 0, device = 0;
 };
 
-// the batch's distinct users (heads of the sorted user keys) now live in the other buffer
-__global__ __launch_bounds__(256) void utable_flip_kernel(const uint32_t *__restrict__ keys, int64_t n, uint32_t kmask,
-                                                          uint8_t *__restrict__ ver)
-{
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n) return;
-    const uint32_t k = keys[t];
-    if (t == 0 || keys[t - 1] != k) ver[k & kmask] ^= 1;
-}
-
 // one wave per row: rows that live in the second buffer are copied back, their version byte is cleared
 __global__ __launch_bounds__(256) void utable_flatten_kernel(float *__restrict__ P, const float *__restrict__ P2, uint8_t *__restrict__ ver,
                                                              int64_t U, int d)
@@ -903,11 +899,7 @@ static int bpr_passes(tfrec_ctx *ctx, const tfrec_batch_slot &sl, float *d_P, fl
         });
     };
     if (!ut) return layout.template operator()<false>();
-    TF_TRY(layout.template operator()<true>());
-    utable_flip_kernel<<<(unsigned)((B + 255) / 256), 256, 0, ctx->stream>>>(keys, B, sl.kmask, ut->ver);
-    TF_HIP(hipGetLastError());
-    tfrec_mark(ctx, "version_flip");
-    return TFREC_OK;
+    return layout.template operator()<true>();      // (the user pass flips the version bytes of the batch's users as it goes)
 }
 
 static int check_utable(tfrec_ctx *ctx, const tfrec_utable *t)
@@ -952,14 +944,19 @@ extern "C" int tfrec_utable_flatten(tfrec_ctx *ctx, tfrec_utable *t)
 extern "C" int tfrec_utable_destroy(tfrec_ctx *ctx, tfrec_utable *t)
 {
     if (!t) return TFREC_OK;
-    TF_TRY(tfrec_utable_flatten(ctx, t));
-    TF_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->aux_stream) TF_HIP(hipStreamSynchronize(ctx->aux_stream));
-    (void)hipFree(t->P2);
-    (void)hipFree(t->ver);
+    // the buffers are released whatever the flatten says (its error, if any, is what the call returns)
+    const int rc = tfrec_utable_flatten(ctx, t);
+    if (ctx) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
+    } else {
+        (void)hipDeviceSynchronize();
+    }
+    if (t->P2) (void)hipFree(t->P2);
+    if (t->ver) (void)hipFree(t->ver);
     t->P2 = nullptr; t->ver = nullptr; t->P = nullptr;
     delete t;
-    return TFREC_OK;
+    return rc;
 }
 
 extern "C" int tfrec_bpr_grad_step(tfrec_ctx *ctx, float *d_P, float *d_Qc, float *d_bc, int64_t U, int64_t Ic, int d,
@@ -1134,9 +1131,9 @@ extern "C" int tfrec_batch_prepare_many(tfrec_ctx *ctx, int slot, int64_t U, int
     TF_REQUIRE(U > 0 && I > 0 && U < (1ll << 31) && I < (1ll << 31), TFREC_EINVAL, "bad table shape");
     TF_REQUIRE(B >= 1 && B < (1ll << 30) && d_users && d_pos && d_neg, TFREC_EINVAL, "bad batch");
     if (!ctx->aux_stream) {
-        // An ordinary stream, not a high-priority one: a high-priority stream whose next packet waits for an event
-        // of the main stream was seen to stall the main stream itself now and then (the wait at the front of the
-        // favoured queue kept the event's own marker from running), and the priority bought no throughput.
+        // An ordinary stream: a high priority bought no throughput when it was measured.  (A hang was once seen in a
+        // run that had this stream at high priority; a stand-alone replay of the event protocol below,
+        // tools/stream_probe.hip, does not stall at either priority, so the priority is not known to be its cause.)
         TF_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
     }
     tfrec_batch_slot &sl = ctx->slots[slot];

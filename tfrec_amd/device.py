@@ -97,9 +97,14 @@ class UserTable:
         return self.P
 
     def close(self):
+        """Flattens, then releases the second row buffer and the version bytes.  After the Device was closed the
+        buffers are still released (without a flatten: nothing can read ``P`` through a closed context anyway)."""
         if self.h and self.dev.h:
-            _lib.check(self.dev.lib.tfrec_utable_destroy(self.dev.h, self.h))
-        self.h = None
+            h, self.h = self.h, None
+            _lib.check(self.dev.lib.tfrec_utable_destroy(self.dev.h, h))
+        elif self.h:
+            h, self.h = self.h, None
+            self.dev.lib.tfrec_utable_destroy(None, h)
 
     def __del__(self):
         try:

@@ -8,11 +8,11 @@ from .BPR import BPR
 
 class DNSBPR(BPR):
     def __init__(self, sess, config, dataset, evaluator):
+        self.neg_num = config["neg_num"]
+        self.n_neg = int(self.neg_num)        # pools of neg_num candidates per positive instead of one negative
         super(DNSBPR, self).__init__(sess, config, dataset, evaluator)
         self.config = config
-        self.neg_num = config["neg_num"]
-        if self._device_sampler is not None:      # pools of neg_num candidates per positive instead of one negative
-            self._device_sampler = DeviceEpochSampler(self.sess, dataset.train_matrix, seed=self._device_sampler.seed, n_neg=self.neg_num)
+        if self._device_sampler is not None:
             n = self._device_sampler.nnz
             self._picked = self.sess.empty(n, np.int32)
             self._picked_shuffled = self.sess.empty(n, np.int32)
@@ -56,6 +56,8 @@ class DNSBPR(BPR):
     def save_model(self):
         """The reference pickles [P, Q, b] to '<data_name>_dnsbpr.pkl' (model/DNSBPR.py:106-109);
         the same file is written here, plus an .npz twin."""
-        P, Q, b = self.mf.parameters()
+        P, Q, b = self.parameters()            # (sharded tables: assembled from the ranks, every rank takes part)
+        if self.rank != 0:
+            return
         save_params("%s_dnsbpr.pkl" % self.config["data_name"], P, Q, b)
         save_params("%s_dnsbpr.npz" % self.config["data_name"], P, Q, b)

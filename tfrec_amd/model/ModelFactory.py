@@ -45,10 +45,25 @@ def parse_value(text):
         return text
 
 
+class _NoLog:
+    def info(self, *a, **k):
+        pass
+
+    debug = warning = error = critical = info
+
+
 class ModelFactory(object):
     def __init__(self, root="."):
         self.root = root
         self.model_dict = {"BPR": BPR, "DNSBPR": DNSBPR, "APR": APR, "Pop": Pop}
+
+    def options(self):
+        """The merged, parsed configuration without any side effect (no log file is opened)."""
+        return self._eval_parameter(*self._read_config())
+
+    def devices(self):
+        """GPUs the run asks for (``devices``, optional, in either ini file; default 1: the reference's single process)."""
+        return int(self.options().get("devices", 1))
 
     def get_model(self):
         tfrec_config, model_config = self._read_config()
@@ -56,7 +71,8 @@ class ModelFactory(object):
         if model_name not in self.model_dict:
             raise KeyError("model '%s' is not part of this package (available: %s)" % (model_name, ", ".join(sorted(self.model_dict))))
         Model = self.model_dict[model_name]
-        Model.logger = self._create_logger(tfrec_config, model_config)
+        # one log file per run: in a run of several processes (one per GPU) rank 0 writes it
+        Model.logger = self._create_logger(tfrec_config, model_config) if int(os.environ.get("RANK", "0")) == 0 else _NoLog()
         return Model, self._eval_parameter(tfrec_config, model_config)
 
     def _read_config(self):

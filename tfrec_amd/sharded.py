@@ -41,9 +41,12 @@ DENSE_ITEM_BYTES = 256 << 20     # item tables up to this size are replicated ra
 
 
 def _via_host(t, group=None):
-    """True under gloo with a device tensor: gloo's own handling of device tensors was seen to hang with two
-    ranks on one GPU (the test set-up), so those collectives are staged through host memory here.  RCCL takes
-    device tensors as they are and orders itself on the stream."""
+    """True under gloo with a device tensor: those collectives are staged through host memory here, with the copy
+    on the current stream.  torch's gloo backend would copy a device tensor on a stream from its HIGH-priority pool
+    and wait for it on the host; with two ranks on one GPU (the test set-up) that starves the other rank's
+    ordinary-priority queues, and both ranks end up parked inside the collective (tools/stream_probe.hip replays it
+    in plain HIP: the stall needs two processes, a high-priority stream and a device-to-host copy on it).  RCCL
+    takes device tensors as they are and orders itself on the stream."""
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
@@ -653,13 +656,22 @@ class ShardedEpochSampler:
     (the draw counter is the global position of the interaction), so the sampled triples do not
     depend on the number of ranks; each rank shuffles its own triples."""
 
-    def __init__(self, dev_or_backend, trainer, train_matrix, seed=2018, n_neg=1):
+    def __init__(self, dev_or_backend, trainer, train_matrix, seed=2018, n_neg=1, shuffle="rank"):
+        """``shuffle``: "rank" -- every rank shuffles its own triples and feeds ``batch_size`` of them per step (the
+        throughput setting: a global batch is ``world * batch_size`` triples); "global" -- every rank derives the ONE
+        permutation a single process would draw for the whole epoch (data/dataiterator.py:52-54) and takes, of
+        every batch of ``batch_size`` consecutive positions, the triples of the users it owns: the global batches
+        are then exactly the single-process batches whatever the number of ranks."""
         self.backend = dev_or_backend if hasattr(dev_or_backend, "uniform_rows") else HipBackend(dev_or_backend)
         self.t = trainer
+        if shuffle not in ("rank", "global"):
+            raise ValueError("shuffle must be 'rank' or 'global'")
+        self.shuffle = shuffle
         from .utils.tools import csr_trained_rows
         csr = csr_trained_rows(train_matrix)       # the users the reference trains (utils/tools.py:52-62)
         lo, hi = trainer.user_range
         self.first = int(csr.indptr[lo])
+        self.total_nnz = int(csr.nnz)
         sub = csr[lo:hi]
         dev = trainer.device
         self.indptr = torch.from_numpy(sub.indptr.astype(np.int64)).to(dev)
@@ -692,20 +704,52 @@ class ShardedEpochSampler:
         be = self.backend
         return be.gather_rows(u, perm) + self.t.user_range[0], be.gather_rows(p, perm), be.gather_rows(n, perm)
 
+    def epoch_global(self, e, batch_size):
+        """This rank's share of the single-process epoch: (users as GLOBAL ids, items, negatives, bounds) where
+        ``bounds[k]:bounds[k+1]`` are this rank's triples of global batch ``k`` (positions ``k*batch_size`` onwards of
+        the one permutation of all ``total_nnz`` interactions), in the order they have in that batch.  One host read."""
+        t, be, N = self.t, self.backend, self.total_nnz
+        n_batches = (N + batch_size - 1) // batch_size
+        u, p, n = self.draw(e)
+        if N == 0:
+            return u, p, n, [0] * (n_batches + 1)
+        perm = be.shuffle_perm(N, self.seed, 2 * e + 1, t.device).to(torch.int64)       # position r holds storage triple perm[r]
+        rel = perm - self.first
+        where = torch.nonzero((rel >= 0) & (rel < self.nnz)).squeeze(1)                  # ascending positions of my triples
+        sel = rel[where].to(torch.int32).contiguous()
+        edges = torch.arange(0, n_batches + 1, device=where.device, dtype=torch.int64) * batch_size
+        bounds = torch.searchsorted(where, edges).tolist()
+        if sel.shape[0] == 0:
+            return u[:0], p[:0], n[:0], bounds
+        return be.gather_rows(u, sel) + t.user_range[0], be.gather_rows(p, sel), be.gather_rows(n, sel), bounds
+
     def train_epoch(self, e, batch_size):
-        """One epoch of collective steps: every rank feeds ``batch_size`` of its own triples per step;
-        ranks that run out keep stepping with empty batches until the longest list is consumed."""
+        """One epoch of collective steps.  ``shuffle="rank"``: every rank feeds ``batch_size`` of its own triples per
+        step; ranks that run out keep stepping with empty batches until the longest list is consumed.
+        ``shuffle="global"``: the steps are the single-process batches of ``batch_size`` triples, each rank feeding
+        the triples of its users."""
         t = self.t
-        users, pos, neg = self.epoch(e)
-        steps = torch.tensor([(self.nnz + batch_size - 1) // batch_size], dtype=torch.int64, device=t.device)
-        if t._coll:
-            _all_reduce(steps, t.group, op=dist.ReduceOp.MAX)
-        n_steps = int(steps.item())
-        batches = []
-        for s in range(n_steps):
-            lo, hi = min(s * batch_size, self.nnz), min((s + 1) * batch_size, self.nnz)
-            batches.append((users[lo:hi], pos[lo:hi], neg[lo:hi]))
-        if t.item_mode == "sharded":
+        apr = not hasattr(t, "plan_steps")              # the APR trainer: its step wants the global batch size
+        if self.shuffle == "global":
+            users, pos, neg, bounds = self.epoch_global(e, batch_size)
+            n_steps = len(bounds) - 1
+            batches = [(users[bounds[s]:bounds[s + 1]], pos[bounds[s]:bounds[s + 1]], neg[bounds[s]:bounds[s + 1]]) for s in range(n_steps)]
+            sizes = [min(batch_size, self.total_nnz - s * batch_size) for s in range(n_steps)]
+        else:
+            users, pos, neg = self.epoch(e)
+            steps = torch.tensor([(self.nnz + batch_size - 1) // batch_size], dtype=torch.int64, device=t.device)
+            if t._coll:
+                _all_reduce(steps, t.group, op=dist.ReduceOp.MAX)
+            n_steps = int(steps.item())
+            batches = []
+            for s in range(n_steps):
+                lo, hi = min(s * batch_size, self.nnz), min((s + 1) * batch_size, self.nnz)
+                batches.append((users[lo:hi], pos[lo:hi], neg[lo:hi]))
+            sizes = [None] * n_steps
+        if apr:
+            for b, size in zip(batches, sizes):
+                t.step(*b, global_batch=size)
+        elif t.item_mode == "sharded":
             # every message size of the epoch is settled here, in one exchange and one host read
             for k, plan in enumerate(t.plan_steps(batches)):
                 t.step_planned(plan, slot=k & 1)
