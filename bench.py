@@ -141,6 +141,32 @@ def other_paths(dev, P, Q, b, U, I, d, B, gen, cuda, steps=10, epoch_pipeline=Tr
     ms = e0.elapsed_time(e1) / 3
     out["device_epoch_pipeline"] = {"triples_per_s": nnz / (ms * 1e-3), "ms_per_epoch": ms, "interactions": nnz,
                                     "note": "sample + shuffle + gather of one epoch; the host sampler of the reference is O(items) per user on one core"}
+    # one whole epoch of model/BPR.py:64-72 on the device: draw + shuffle + gather, then every step of the epoch
+    # (batches of B triples, the last one short), on a versioned user table with the index of the next batch sorted ahead
+    Pe, Qe, be_ = P.clone(), Q.clone(), b.clone()
+    ut = dev.user_table(Pe)
+    bounds = list(range(0, nnz, B)) + [nnz]
+
+    def whole_epoch(e):
+        epoch(e)
+        dev.prepare_batch(0, U, I, su[bounds[0]:bounds[1]], sp[bounds[0]:bounds[1]], sn[bounds[0]:bounds[1]])
+        for k in range(len(bounds) - 1):
+            if k + 2 < len(bounds):
+                lo, hi = bounds[k + 1], bounds[k + 2]
+                dev.prepare_batch((k + 1) & 1, U, I, su[lo:hi], sp[lo:hi], sn[lo:hi])
+            dev.bpr_sgd_step_prepared_v(k & 1, ut, Qe, be_, 0.01, 0.05)
+        ut.flatten()
+    whole_epoch(10)
+    torch.cuda.synchronize()
+    e0.record()
+    for e in range(11, 14):
+        whole_epoch(e)
+    e1.record(); torch.cuda.synchronize()
+    ut.close()
+    ms = e0.elapsed_time(e1) / 3
+    out["epoch_end_to_end"] = {"epoch_triples_per_s": nnz / (ms * 1e-3), "ms_per_epoch": ms, "interactions": nnz, "steps": len(bounds) - 1,
+                               "batch": B, "note": "draw + shuffle + gather + every BPR step of the epoch + flatten, one stream, nothing overlapped "
+                                                   "between epochs"}
     return out
 
 
@@ -301,26 +327,84 @@ def cpu_baseline_eval(I, d, k, n_users=1024, threads=16):
             "sample": "%d users x %d items, d=%d, k=%d (oracle/mf_oracle.c, scalar C)" % (n_users, I, d, k)}
 
 
-def launch_ranks(n):
-    """`python bench.py --gpus N` without a launcher: start N ranks of this script as child processes (one per
-    GPU, the environment torch.distributed.run would give them) and pass rank 0's JSON line through.  The
-    parent never touches the GPU and replaces no process image."""
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, WORLD_SIZE=str(n), RANK=str(r), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
-    sys.stdout.flush()
-    return next((c for c in codes if c), 0)
+def large_shape_sharded(dev, cuda, world, rank, scale, barrier, max_over_ranks, steps=8):
+    """The largest configuration's layout over the ranks (weak scaling: per GPU 1.25M users x 250k items of d=128 -- 10M x 2M
+    on eight GPUs -- and 4M triples per step): every table sharded, planned all-to-all steps (with the split of a step
+    into fetch / compute / return / apply from stream events), the DNS draw of an epoch with 32 candidates per positive
+    (candidate pools, one all-gather of the item shards, selection), and the item-sharded bf16 top-100 evaluation."""
+    from tfrec_amd.device import SCORE_BF16
+    from tfrec_amd.sharded import PhaseTimers, ShardedBprTrainer, ShardedEpochSampler, ShardedEvaluator
+    d = 128
+    nu, ni, B = max(int(1_250_000 * scale), 1024), max(int(250_000 * scale), 512), max(int((1 << 22) * scale), 4096)
+    U, I = nu * world, ni * world
+    tr = ShardedBprTrainer(dev, U, I, d, 0.01, 0.05, seed=4242, device=cuda, item_mode="sharded")
+    lo, hi = tr.user_range
+    g = torch.Generator(device=cuda)
+    g.manual_seed(4242 + rank)
+    nb = 4
+    users = torch.randint(0, hi - lo, (nb * B,), device=cuda, generator=g, dtype=torch.int32) + lo
+    pos = zipf_items(I, nb * B, g, cuda)
+    neg = torch.randint(0, I, (nb * B,), device=cuda, generator=g, dtype=torch.int32)
+    batches = [(users[o:o + B], pos[o:o + B], neg[o:o + B]) for o in range(0, nb * B, B)]
+    res = {"shape": "%d GPUs x (%d users, %d items), d=%d, %d triples per step and GPU; every table sharded by rows" % (world, nu, ni, d, B)}
+
+    def timed(fn, reps):
+        fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        barrier()
+        return max_over_ranks((time.perf_counter() - t0) / reps)
+
+    def epoch_of_steps():
+        tr.run_planned(tr.plan_steps(batches))
+    dt = timed(epoch_of_steps, max(steps // nb, 1)) / nb
+    per_gpu = B * (24 * d + 28) / dt / 1e9
+    tr._timers = PhaseTimers()
+    epoch_of_steps()
+    split = {k: v / nb for k, v in tr._timers.totals().items()}
+    tr._timers = None
+    res["bpr_sgd_step"] = {"triples_per_s": world * B / dt, "ms_per_step": dt * 1e3, "split_ms": split,
+                           "note": "plan (de-duplication, counts and ids exchanged once for the %d steps) + steps; split: fetch = owners' rows "
+                                   "gathered and exchanged, compute = local step, return = gradient sums exchanged, apply = owners' update" % nb,
+                           "roofline": {"bound": "hbm", "achieved": per_gpu, "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU", "frac": per_gpu / HBM_PEAK_GBS,
+                                        "algorithmic_bytes_per_triple": 24 * d + 28}}
+    del users, pos, neg, batches
+    # DNS: the epoch's candidate pools (32 per positive), the item shards gathered once, the best-scored candidate
+    deg, Cn = 10, 32
+    indptr = torch.arange(0, deg * (nu + 1), deg, device=cuda, dtype=torch.int64)
+    indices = torch.sort(torch.randint(0, I, (nu, deg), device=cuda, generator=g, dtype=torch.int32), dim=1).values.reshape(-1).contiguous()
+    sm = ShardedEpochSampler.from_local_csr(dev, tr, indptr, indices, first=rank * nu * deg, total_nnz=U * deg, seed=2018, n_neg=Cn)
+    state = {"e": 0}
+
+    def draw():
+        state["e"] += 1
+        sm.draw(state["e"])
+    dt = timed(draw, 2)
+    per = (Cn + 1) * 4 * d + 8 * Cn
+    gbs = per * nu * deg / dt / 1e9
+    res["dns_epoch_draw"] = {"positives_per_s": world * nu * deg / dt, "ms": dt * 1e3, "positives_per_gpu": nu * deg, "candidates": Cn,
+                             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s per GPU", "frac": gbs / HBM_PEAK_GBS,
+                                          "algorithmic_bytes_per_positive": per}}
+    del sm, indptr, indices
+    # evaluation: bf16 scores, top 100, item-sharded; 131072 evaluated users per GPU
+    g2 = torch.Generator(device=cuda)
+    g2.manual_seed(777)                                      # the same lists on every rank
+    n_eval, k, tdeg = min(max(int(131072 * scale), 256) * world, U), 100, 3
+    eu = (torch.arange(n_eval, device=cuda, dtype=torch.int64) * U // n_eval).to(torch.int32)
+    tptr = torch.arange(0, deg * (U + 1), deg, device=cuda, dtype=torch.int64)
+    tidx = torch.sort(torch.randint(0, I, (U, deg), device=cuda, generator=g2, dtype=torch.int32), dim=1).values.reshape(-1).contiguous()
+    eptr = torch.arange(0, tdeg * (U + 1), tdeg, device=cuda, dtype=torch.int64)
+    eidx = torch.sort(torch.randint(0, I, (U, tdeg), device=cuda, generator=g2, dtype=torch.int32), dim=1).values.reshape(-1).contiguous()
+    fresh = ShardedBprTrainer(dev, U, I, d, 0.01, 0.05, seed=777, device=cuda, item_mode="sharded")
+    se = ShardedEvaluator(dev, fresh, (tptr, tidx), (eptr, eidx), eu, top_k=k, mode=SCORE_BF16, chunk_users=max(n_eval // world, 1))
+    dt = timed(se.evaluate, 1)
+    tf = 2.0 * I * d * n_eval / dt / 1e12
+    res["eval_bf16_top100"] = {"users_per_s": n_eval / dt, "ms": dt * 1e3, "users": n_eval, "items": I, "layout": se.layout + "-sharded",
+                               "roofline": {"bound": "mfma", "achieved": tf / world, "peak": MFMA_PEAK_TFLOPS["bf16"], "unit": "TFLOP/s per GPU",
+                                            "frac": tf / world / MFMA_PEAK_TFLOPS["bf16"]}}
+    return res
 
 
 def main():
@@ -352,10 +436,13 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="testing: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--plain-table", action="store_true", help="single GPU: plain user table (pre-step rows staged per triple) instead of the versioned one")
     ap.add_argument("--no-extras", action="store_true", help="skip the timing of the reference batch size (512 triples per step)")
+    ap.add_argument("--large-scale", type=float, default=1.0, help="testing: shrink the sharded large-shape block (N > 1) by this factor")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(launch_ranks(args.gpus))          # before anything initialises the GPU in this process
+        # before anything initialises the GPU in this process; the ranks are fresh child processes, all of them watched
+        from tfrec_amd.launch import launch_ranks
+        raise SystemExit(launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -368,15 +455,8 @@ def main():
     torch.cuda.set_device(local_rank)
     cuda = torch.device("cuda", local_rank)
     if world > 1 or args.force_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=cuda)
-        else:
-            dist.init_process_group("gloo")
+        from tfrec_amd.launch import init_process_group
+        init_process_group(args.backend, device=cuda)
 
     from tfrec_amd.device import Device, SCORE_F32, SCORE_BF16
     stream = torch.cuda.Stream(device=cuda)
@@ -459,10 +539,14 @@ def main():
                 def step(s):
                     if not plans:
                         plans.extend(trainer.plan_steps([batch(s + i) for i in range(n_batches)]))
-                    trainer.step_planned(plans.pop(0), slot=s & 1)
+                    plan = plans.pop(0)
+                    trainer.step_planned(plan, slot=s & 1, next_plan=plans[0] if plans else None)
 
         def max_over_ranks(x):
-            # (a host tensor under gloo, whose handling of device tensors is unreliable with ranks that share a GPU)
+            if not (world > 1 or args.force_dist):
+                return x
+            # (a host tensor under gloo: torch's gloo backend copies device tensors on high-priority streams, which starves
+            # the other rank when ranks share a GPU)
             t = torch.tensor([x], device=cuda if args.backend == "nccl" else "cpu", dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             return float(t.item())
@@ -579,6 +663,9 @@ def main():
                 del apr
                 return res
             guarded("other_paths", sharded_apr)
+        if trainer is not None and not args.no_large:
+            torch.cuda.empty_cache()
+            guarded("large_shape", lambda: large_shape_sharded(dev, cuda, world, rank, args.large_scale, barrier, max_over_ranks))
         if rank == 0 and world == 1 and not args.force_sharded:
             # ---- roofline of the step's kernels: HIP events recorded by the library on its own stream
             # (un-pipelined steps, so that the index phase is timed on the same stream as the row passes)
@@ -609,7 +696,6 @@ def main():
                 "measured_copy_peak": MEASURED_COPY_GBS, "frac_of_measured_copy_peak": achieved / MEASURED_COPY_GBS,
                 "device_ms_per_step": dev_ms / args.steps,
                 "phases_ms": acc, "dominant_phase": dom,
-                "dominant_phase_algorithmic_GBs": B * (16 * d + 20) / (acc[dom] * 1e-3) / 1e9 if dom == "user_tile" else None,
             }
             if not args.no_extras:
                 # positives uniform over the items instead of Zipf: the bound without hot rows (fewer duplicates,
@@ -638,6 +724,33 @@ def main():
                                              "frac": B * alg_bytes_per_triple / (ums * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                              "note": "un-pipelined step, positives uniform over the items (no hot rows)"}
                 del upos
+                # batches of 2^20 triples on the same tables: about one occurrence per user, so no user row is shared
+                # between the triples of a batch (the prepared, pipelined path of the headline)
+                Bs = 1 << 20
+                if B > Bs and B % Bs == 0:
+                    nsm = (n_batches * B) // Bs
+
+                    def sm(k):
+                        o = (k % nsm) * Bs
+                        return users[o:o + Bs], pos[o:o + Bs], neg[o:o + Bs]
+                    ut_s = dev.user_table(P) if ut is not None else None
+                    dev.prepare_batches(0, U, I, *sm(0), 1)
+                    for k in range(64 + 8):
+                        if k == 8:
+                            e2.record(stream)
+                        dev.prepare_batches((k + 1) & 1, U, I, *sm(k + 1), 1)
+                        if ut_s is not None:
+                            dev.bpr_sgd_step_prepared_v(k & 1, ut_s, Q, b, lr, reg)
+                        else:
+                            dev.bpr_sgd_step_prepared(k & 1, P, Q, b, lr, reg)
+                    e3.record(stream)
+                    torch.cuda.synchronize()
+                    if ut_s is not None:
+                        ut_s.close()
+                    sms = e2.elapsed_time(e3) / 64
+                    out["batch_2p20"] = {"ms_per_step": sms, "triples_per_s": Bs / (sms * 1e-3), "batch": Bs,
+                                         "frac": Bs * alg_bytes_per_triple / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                         "note": "same tables and path as the headline, 2^20 triples per step (about one occurrence per user)"}
                 # the reference batch size (conf/BPR.ini:4: 512 triples per step): five short kernels, latency-bound
                 small = 512
                 ref = {}

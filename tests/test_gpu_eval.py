@@ -388,3 +388,26 @@ def test_every_kernel_instantiation(dev, mode_name, d, k):
     assert clear.mean() > 0.5
     assert np.array_equal(ids[clear], order[:, :k][clear])
     assert (np.diff(sc, axis=1) <= 0).all()
+
+
+@pytest.mark.parametrize("case", ["small", "subset", "short_truth", "c1_shape"])
+def test_sums_only_metrics_agree_with_the_per_user_curves(dev, golden_eval, case):
+    """The two ways tfrec_rank_metrics_sums forms its sums -- straight from the rank lists (no per-user table; precision,
+    NDCG and MRR then come from integer hit counts in float64) and from the per-user float32 curves (each curve
+    rounded to float per user, as evaluator/backend/cpp/metrics.h:59-100 does) -- agree to 2e-7 relative, and both
+    means agree with the reference's float32 means of the golden cases to 5e-6."""
+    g = {k.split("/", 1)[1]: v for k, v in golden_eval.items() if k.startswith(case + "/")}
+    users = dev.array(g["test_users"], np.int32)
+    test = dcsr(dev, g["test_indptr"], g["test_indices"])
+    n = len(g["test_users"])
+    for k in g["k_list"]:
+        k = int(k)
+        ids = dev.array(g["ranks_k%d" % k].astype(np.int32))
+        direct = dev.rank_metrics_sums(ids, users, k, test).numpy()
+        rows = dev.empty((n, 5 * k), np.float32)
+        via_rows = dev.rank_metrics_sums(ids, users, k, test, per_user=rows).numpy()
+        dev.synchronize()
+        np.testing.assert_allclose(direct, via_rows, rtol=2e-7, atol=1e-9)
+        np.testing.assert_allclose(via_rows, rows.numpy().astype(np.float64).sum(0), rtol=1e-12)
+        for sums in (direct, via_rows):
+            np.testing.assert_allclose((sums / n).reshape(5, k), g["metrics_k%d" % k], rtol=5e-6, atol=1e-7)

@@ -116,3 +116,36 @@ def test_dnsbpr_with_the_device_sampler_follows_the_oracle_schedule(dev, oracle,
     P1, Q1, b1 = model.mf.parameters()
     for a, c in ((P1, P), (Q1, Q), (b1, b)):
         np.testing.assert_allclose(a, c, rtol=2e-4, atol=2e-6)
+
+
+def test_apr_with_the_device_sampler_follows_the_oracle_schedule(dev, oracle, tmp_path):
+    """APR with ``sampler = device`` (model/APR.py:156-184 with the epoch drawn and shuffled on the GPU): two epochs
+    equal the oracle's APR steps over the oracle-drawn, oracle-shuffled epochs."""
+    from test_gpu_models import synthetic, _Log
+    from tfrec_amd.evaluator import FoldOutEvaluator
+    from tfrec_amd.model import APR
+    from tfrec_amd.utils import save_params
+    ds = synthetic(6, U=150, I=120)
+    U, I = ds.train_matrix.shape
+    rng = np.random.default_rng(4)
+    P = rng.uniform(-0.3, 0.3, (U, 20)).astype(np.float32); Q = rng.uniform(-0.3, 0.3, (I, 20)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, I).astype(np.float32)
+    pre = str(tmp_path / "pre.npz")
+    save_params(pre, P, Q, b)
+    ev = FoldOutEvaluator(ds.train_matrix, ds.test_matrix, top_k=10)
+    cfg = {"factors_num": 20, "lr": 0.05, "reg": 0.01, "reg_adv": 1, "eps": 0.05, "epochs": 2, "batch_size": 128, "pretrain_file": pre,
+           "sampler": "device", "seed": 17}
+    APR.logger = _Log()
+    model = APR(dev, cfg, ds, ev)
+    model.train_model()
+    tr = ds.train_matrix
+    aP, aQ, ab = [np.full_like(x, 0.1) for x in (P, Q, b)]
+    ws = oracle.Workspace(U, I, 20)
+    for e in range(2):
+        u, p, n, _ = oracle.sample_negatives(tr.indptr.astype(np.int64), tr.indices.astype(np.int32), U, I, 1, 17, 2 * e)
+        perm = oracle.shuffle_perm(tr.nnz, 17, 2 * e + 1)
+        u, p, n = u[perm], p[perm], n[perm].ravel()
+        for lo in range(0, len(u), 128):
+            oracle.apr_step(P, Q, b, aP, aQ, ab, u[lo:lo + 128], p[lo:lo + 128], n[lo:lo + 128], 0.05, 0.01, 1.0, 0.05, ws=ws)
+    for got, want in zip(model.mf.parameters(), (P, Q, b)):
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-6)

@@ -127,11 +127,20 @@ def test_param_files(tmp_path):
                 got = read_param_pickle_safely(path)
                 for x, y in zip(got, (P2, Q2, b2)):
                     assert x.dtype == np.float32 and x.shape == y.shape and np.array_equal(x, y.astype(np.float32)), (U, I, d, dt, proto)
+            # read-only arrays: protocol 5 then writes their buffers as bytes, not as a bytearray
+            for a in (P2, Q2, b2):
+                a.setflags(write=False)
+            with open(path, "wb") as f:
+                pickle.dump([P2, Q2, b2], f, protocol=5)
+            for x, y in zip(read_param_pickle_safely(path), (P2, Q2, b2)):
+                assert x.shape == y.shape and np.array_equal(x, y.astype(np.float32)), (U, I, d, dt, "read-only")
+    # globals other than numpy's are refused under every protocol (4 and 5 name them by two texts and STACK_GLOBAL)
     bad = str(tmp_path / "bad.pkl")
-    with open(bad, "wb") as f:
-        pickle.dump([os.path.join, 1], f)
-    with pytest.raises(ValueError):
-        read_param_pickle_safely(bad)
+    for proto in (2, 3, 4, 5):
+        with open(bad, "wb") as f:
+            pickle.dump([os.path.join, 1], f, protocol=proto)
+        with pytest.raises(ValueError, match="not a plain numpy"):
+            read_param_pickle_safely(bad)
 
 
 def test_checkpoint_round_trip(tmp_path):

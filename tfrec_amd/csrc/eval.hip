@@ -493,6 +493,24 @@ struct ScoreWave<256, true, CAP> { static constexpr int UW = 1, NW = 8; };
 template <int CAP>
 struct ScoreWave<64, false, CAP> { static constexpr int UW = 1, NW = 8; };
 
+// staging of item tiles in the sixteen-wave bf16 kernels: 1 = ring of short tiles with per-slot counters (see
+// ScoreGeom::RING), 0 = two long tiles and a workgroup barrier per tile
+#ifndef TF_EVAL_RING
+#define TF_EVAL_RING 0
+#endif
+#ifndef TF_EVAL_AFRAG_AHEAD
+#define TF_EVAL_AFRAG_AHEAD 0
+#endif
+#ifndef TF_EVAL_RING_TI
+#define TF_EVAL_RING_TI 64
+#endif
+#ifndef TF_EVAL_RING_SLOTS
+#define TF_EVAL_RING_SLOTS 6
+#endif
+#ifndef TF_EVAL_RING_AHEAD
+#define TF_EVAL_RING_AHEAD 3
+#endif
+
 // LDS bytes of an instantiation with tiles of `ti` items
 constexpr int score_lds_bytes(int ti, int rowb, int nw, int cap) { return 2 * ti * rowb + 2 * ti * 4 + nw * cap * 8 + 1536; }
 
@@ -504,15 +522,32 @@ struct ScoreGeom {
     // the barriers) where the CU's 160 KB hold two of them beside the sort buffers, else twice as long
     static constexpr int TI0 = D * ESZ >= 256 ? 64 : 128;
     static constexpr bool ALONE = ScoreWave<D, BF16, CAP>::NW == 16 || ScoreWave<D, BF16, CAP>::UW > 1;   // one workgroup per CU
-    static constexpr int TI = !ALONE ? TI0
+    static constexpr int TI_BARRIER = !ALONE ? TI0
                               : (score_lds_bytes(3 * TI0, ROWB, ScoreWave<D, BF16, CAP>::NW, CAP) <= 160 * 1024 &&
                                  (3 * TI0 * (D * ESZ / 16)) % (64 * ScoreWave<D, BF16, CAP>::NW) == 0 ? 3 * TI0 : 2 * TI0);
     static constexpr int CPR = D * ESZ / 16;                 // 16-byte chunks per row
     static constexpr int NW = ScoreWave<D, BF16, CAP>::NW, NT = 64 * NW;   // waves / threads per workgroup
+    // RING: the sixteen-wave bf16 instantiations stage item tiles through a ring of NSLOT short tiles guarded by
+    // per-slot counters in LDS instead of two long tiles and a workgroup barrier per tile: a wave that is held up
+    // (a compaction, a run of insertions) no longer stops the other fifteen at the next tile boundary; it may fall
+    // min(PF, NSLOT - PF) tiles behind before anybody waits for it (PF = how many tiles ahead a tile is staged).
+    static constexpr bool RING = TF_EVAL_RING != 0 && BF16 && ALONE && ScoreWave<D, BF16, CAP>::UW == 1;
+    static constexpr int TI = RING ? (TF_EVAL_RING_TI > NT / CPR ? TF_EVAL_RING_TI : NT / CPR) : TI_BARRIER;   // (at least a chunk per thread)
+    // as many slots as asked for and the LDS holds beside the sort buffers (at least three); a tile is staged half a ring ahead
+    static constexpr int ring_slots()
+    {
+        int n = TF_EVAL_RING_SLOTS;
+        while (n > 3 && n * (TI * ROWB + TI * 4) + NW * CAP * 8 + 1536 > 160 * 1024) --n;
+        return n;
+    }
+    static constexpr int NSLOT = RING ? ring_slots() : 2;
+    static constexpr int PF = !RING ? 1 : (NSLOT == TF_EVAL_RING_SLOTS ? TF_EVAL_RING_AHEAD : NSLOT / 2);
     static constexpr int NLD = TI * CPR / NT;                // chunks per thread per tile
     static_assert(NLD >= 1 && NLD * NT == TI * CPR && NT >= TI, "tile does not divide over the workgroup");
+    static_assert(!RING || (PF >= 1 && PF < NSLOT), "a tile is staged 1 .. NSLOT-1 tiles ahead");
     static constexpr int QBYTES = TI * ROWB;
-    static constexpr int LDS_BYTES = 2 * QBYTES + 2 * TI * 4 + NW * CAP * 8 + 1536;
+    static constexpr int LDS_BYTES = NSLOT * QBYTES + NSLOT * TI * 4 + NW * CAP * 8 + 1536;
+    static_assert(LDS_BYTES <= 160 * 1024, "the staging buffers do not fit the CU's LDS");
 };
 
 // Developer ablations of the scan loop (never defined in the shipped build): 1 = no list filter,
@@ -529,9 +564,14 @@ __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk
     constexpr int TI = G::TI, ROWB = G::ROWB, CPR = G::CPR, NLD = G::NLD, ESZ = G::ESZ;
     constexpr int UW = ScoreWave<D, BF16, CAP>::UW, NT = G::NT, UB = 32 * G::NW * UW;   // user sets per wave, threads and users per workgroup
     extern __shared__ __align__(16) char lds[];
-    char *qbuf = lds;                                                   // [2][TI*ROWB]
-    float *bias = reinterpret_cast<float *>(lds + 2 * G::QBYTES);        // [2][TI]
-    uint64_t *sortbuf = reinterpret_cast<uint64_t *>(bias + 2 * TI);     // [waves][CAP]
+    constexpr bool RING = G::RING;
+    constexpr int NSLOT = G::NSLOT, PF = G::PF;
+    char *qbuf = lds;                                                   // [NSLOT][TI*ROWB]
+    float *bias = reinterpret_cast<float *>(lds + NSLOT * G::QBYTES);    // [NSLOT][TI]
+    uint64_t *sortbuf = reinterpret_cast<uint64_t *>(bias + NSLOT * TI); // [waves][CAP]
+    // ring: per slot, how many waves have stored their share of a tile (ready) and how many have finished reading
+    // one (done); the counts only grow, a slot's n-th use waits for n * waves
+    uint32_t *ring_ready = reinterpret_cast<uint32_t *>(sortbuf + G::NW * CAP), *ring_done = ring_ready + NSLOT;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int uj = lane & 31, h = lane >> 5;
@@ -614,13 +654,40 @@ __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk
     volatile uint64_t *mysort = sortbuf + wave * CAP;
     const int lane_row_off = uj * ROWB, lane_bias_off = 4 * h;     // this lane's place in an LDS tile
 
-    load_tile(it0);
-    store_tile(0);
-    __syncthreads();
     const int64_t n_steps = (it1 - it0 + TI - 1) / TI;
+    auto ring_signal = [&](uint32_t *c) {
+        // (a wave's LDS operations execute in order: the count moves after the wave's own stores / reads of the slot)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto ring_wait = [&](uint32_t *c, uint32_t target) {
+        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
+            __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    if constexpr (RING) {
+        if (tid < 2 * NSLOT) ring_ready[tid] = 0;
+        __syncthreads();
+        for (int p = 0; p < PF && p < n_steps; ++p) {       // the first PF tiles: their slots are fresh
+            load_tile(it0 + (int64_t)p * TI);
+            store_tile(p);
+            ring_signal(&ring_ready[p]);
+        }
+    } else {
+        load_tile(it0);
+        store_tile(0);
+        __syncthreads();
+    }
+    int ring_slot = 0, ring_nslot = PF % NSLOT;             // slot of this step's tile, slot of the tile staged during it
+    uint32_t ring_use = 1, ring_nuse = PF / NSLOT;           // ordinal of this step's use of its slot; completed uses of the other
     for (int64_t step = 0; step < n_steps; ++step) {
-        const int buf = (int)(step & 1);
-        if (TF_EVAL_ABLATE < 3 && step + 1 < n_steps) load_tile(it0 + (step + 1) * TI);
+        const int buf = RING ? ring_slot : (int)(step & 1);
+        if constexpr (RING) {
+            if (step + PF < n_steps) load_tile(it0 + (step + PF) * TI);
+            ring_wait(&ring_ready[buf], (uint32_t)G::NW * ring_use);
+        } else {
+            if (TF_EVAL_ABLATE < 3 && step + 1 < n_steps) load_tile(it0 + (step + 1) * TI);
+        }
         const char *qb = qbuf + buf * G::QBYTES;
         const float *bb = bias + buf * TI;
 #pragma unroll 1
@@ -636,9 +703,21 @@ __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk
             }
             const char *arow = qb + lane_row_off + sb * (32 * ROWB);
             if constexpr (BF16) {
+#if TF_EVAL_AFRAG_AHEAD
+                // all of the block's A fragments requested before the first matrix instruction: one LDS round trip per
+                // block of 32 items instead of one per pair of fragments
+                bf16x8 avs[D / 16];
+#pragma unroll
+                for (int ks = 0; ks < D / 16; ++ks) avs[ks] = *reinterpret_cast<const bf16x8 *>(arow + (16 * ks + 8 * h) * 2);
+                __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
                 for (int ks = 0; ks < D / 16; ++ks) {
+#if TF_EVAL_AFRAG_AHEAD
+                    const bf16x8 av = avs[ks];
+#else
                     const bf16x8 av = TF_EVAL_ABLATE >= 2 ? pb[0][ks] : *reinterpret_cast<const bf16x8 *>(arow + (16 * ks + 8 * h) * 2);
+#endif
 #if TF_EVAL_ABLATE >= 6
                     {   // timing only: the same flops as two 16x16x32 instructions (results meaningless)
                         typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -732,7 +811,19 @@ __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk
                 TF_PROF_ADD(2, prof_t_cmp);
             }
         }
-        if (TF_EVAL_ABLATE < 3) {
+        if constexpr (RING) {
+            [[maybe_unused]] const unsigned long long prof_t_bar = TF_PROF_T();
+            ring_signal(&ring_done[buf]);
+            if (step + PF < n_steps) {
+                // the slot's previous tile (NSLOT tiles before the one staged now) must have been read by every wave
+                ring_wait(&ring_done[ring_nslot], (uint32_t)G::NW * ring_nuse);
+                store_tile(ring_nslot);
+                ring_signal(&ring_ready[ring_nslot]);
+            }
+            if (++ring_slot == NSLOT) { ring_slot = 0; ++ring_use; }
+            if (++ring_nslot == NSLOT) { ring_nslot = 0; ++ring_nuse; }
+            TF_PROF_ADD(3, prof_t_bar);
+        } else if (TF_EVAL_ABLATE < 3) {
             [[maybe_unused]] const unsigned long long prof_t_bar = TF_PROF_T();
             if (step + 1 < n_steps) store_tile(buf ^ 1);
             __syncthreads();

@@ -42,6 +42,10 @@ __device__ __forceinline__ uint32_t clamp_index(int32_t v, uint32_t n, bool *bad
 #ifndef TF_DEPTH_ITEM
 #define TF_DEPTH_ITEM 4
 #endif
+// developer comparison: 1 = flip the version bytes in a kernel of their own after both passes instead of in the user pass
+#ifndef TF_FLIP_KERNEL
+#define TF_FLIP_KERNEL 0
+#endif
 #ifndef TF_SHORT_TILES_MAX_B
 #define TF_SHORT_TILES_MAX_B 131072
 #endif
@@ -139,7 +143,7 @@ struct BprUserPol {
         // entry() that looks this user's byte up has been staged: entries are staged by the tile that holds them,
         // and a run that is applied in the tile kernel lies in that one tile.  The item pass does not read the
         // bytes (the triples' records carry the pre-step location).
-        if constexpr (VER) if (gl == 0) a.ver[key & a.kmask] = v ? 0 : 1;
+        if constexpr (VER && !TF_FLIP_KERNEL) if (gl == 0) a.ver[key & a.kmask] = v ? 0 : 1;
     }
 };
 
@@ -804,6 +808,18 @@ struct tfrec_utable {
     int d = 0, device = 0;
 };
 
+#if TF_FLIP_KERNEL
+// the batch's distinct users (heads of the sorted user keys) now live in the other buffer
+__global__ __launch_bounds__(256) void utable_flip_kernel(const uint32_t *__restrict__ keys, int64_t n, uint32_t kmask,
+                                                          uint8_t *__restrict__ ver)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t k = keys[t];
+    if (t == 0 || keys[t - 1] != k) ver[k & kmask] ^= 1;
+}
+#endif
+
 // one wave per row: rows that live in the second buffer are copied back, their version byte is cleared
 __global__ __launch_bounds__(256) void utable_flatten_kernel(float *__restrict__ P, const float *__restrict__ P2, uint8_t *__restrict__ ver,
                                                              int64_t U, int d)
@@ -899,7 +915,15 @@ static int bpr_passes(tfrec_ctx *ctx, const tfrec_batch_slot &sl, float *d_P, fl
         });
     };
     if (!ut) return layout.template operator()<false>();
+#if TF_FLIP_KERNEL
+    TF_TRY(layout.template operator()<true>());
+    utable_flip_kernel<<<(unsigned)((B + 255) / 256), 256, 0, ctx->stream>>>(keys, B, sl.kmask, ut->ver);
+    TF_HIP(hipGetLastError());
+    tfrec_mark(ctx, "version_flip");
+    return TFREC_OK;
+#else
     return layout.template operator()<true>();      // (the user pass flips the version bytes of the batch's users as it goes)
+#endif
 }
 
 static int check_utable(tfrec_ctx *ctx, const tfrec_utable *t)

@@ -23,10 +23,10 @@ Layout
     perturbation gradients and one of the Adagrad gradients.
   * evaluation with the replicated item table: user-sharded -- every rank evaluates the users it owns
     against all items, only the metric sums are all-reduced.
-  * evaluation: item-sharded.  The factor rows of a chunk of evaluated users are broadcast from
-    their owner, every rank takes the top-k over its own items (global ids), the lists are
-    all-gathered and merged under the total order (score desc, id asc) -- so the result is that
-    of an unsharded evaluation -- and the metric sums are all-reduced.
+  * evaluation: item-sharded.  The factor rows of a round of evaluated users (a chunk per owner) are
+    all-gathered, every rank takes the top-k over its own items (global ids), one all-to-all sends each
+    list to the owner of its user, who merges the ranks' lists under the total order (score desc, id asc)
+    -- so the result is that of an unsharded evaluation -- and the metric sums are all-reduced.
 
 All device arithmetic goes through a *backend* object.  The product backend is ``HipBackend``
 (the C ABI on this rank's GPU, torch CUDA tensors as buffers).  Tests inject a CPU backend to
@@ -221,6 +221,27 @@ class HipBackend:
         self.dev.synchronize()
 
 
+class PhaseTimers:
+    """Stream-event marks of the phases of a planned step (benchmarks only): ``mark(name)`` records an event on the
+    current stream; ``totals()`` waits and returns the milliseconds spent before each named mark, summed over steps."""
+
+    def __init__(self):
+        self.events = []
+
+    def mark(self, name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.events.append((name, e))
+
+    def totals(self):
+        torch.cuda.synchronize()
+        out = {}
+        for (n0, e0), (n1, e1) in zip(self.events[:-1], self.events[1:]):
+            if n1 != "start":
+                out[n1] = out.get(n1, 0.0) + e0.elapsed_time(e1)
+        return out
+
+
 def make_device(local_rank):
     """A Device whose stream is also torch's current stream on that GPU, so that torch ops (the
     exchange plumbing) and library kernels are ordered without extra synchronisation."""
@@ -287,6 +308,7 @@ class ShardedBprTrainer:
             self.b = torch.zeros(max(ni, 1), dtype=torch.float32, device=device)[:ni]
         assert self.P.shape[0] == nu and self.Q.shape[0] == ni
         self._mark = None
+        self._timers = None         # a PhaseTimers object while a benchmark wants the split of a planned step
         self._pending = {}          # slot -> index tensors of a prepared batch, alive until its step is enqueued
         if overlap_chunks is None:
             overlap_chunks = 2 if (self._coll and self.world > 1 and dist.get_backend(group) == "nccl") else 1
@@ -396,8 +418,9 @@ class ShardedBprTrainer:
         """Plans the lookups of a list of upcoming steps (collective).  ``batches``: this rank's (users, pos, neg)
         per step, global ids, every user inside ``user_range``; empty batches allowed.  Per step the library
         de-duplicates the items (marks + prefix sum, ascending, hence grouped by owner) and counts them per owner;
-        ALL the counts cross in one all-to-all and are read back once, so that the steps themselves
-        (``step_planned``) know every message size without touching the host again."""
+        ALL the counts cross in one all-to-all and are read back once, and then ALL the requested ids cross in a
+        second one (they depend on the batches alone, not on the parameters), so that a step itself
+        (``step_planned``) exchanges only rows and gradient sums and never touches the host."""
         assert self.item_mode == "sharded"
         W, dev = self.world, self.device
         S = len(batches)
@@ -417,32 +440,72 @@ class ShardedBprTrainer:
         for s, p in enumerate(plans):
             p["send"], p["recv"] = both[0, s].tolist(), both[1, s].tolist()
             p["uniq"] = p["uniq"][: sum(p["send"])]
+        # the ids of every step to their owners, in one exchange: the block for owner o is the steps' shares for o,
+        # one after the other; what arrives from rank r splits the same way by the counts r announced
+        if S:
+            offs = [np.concatenate([[0], np.cumsum(p["send"])]).tolist() for p in plans]
+            send = torch.cat([plans[s]["uniq"][offs[s][o]:offs[s][o + 1]] for o in range(W) for s in range(S)]) if S * W else plans[0]["uniq"][:0]
+            send_counts = [sum(plans[s]["send"][o] for s in range(S)) for o in range(W)]
+            recv_counts = [sum(plans[s]["recv"][r] for s in range(S)) for r in range(W)]
+            got = self._a2a(send, send_counts, recv_counts)
+            pos_, pieces = 0, [[None] * W for _ in range(S)]
+            for r in range(W):
+                for s in range(S):
+                    n = plans[s]["recv"][r]
+                    pieces[s][r] = got[pos_:pos_ + n]
+                    pos_ += n
+            for s, p in enumerate(plans):
+                p["local"] = (torch.cat(pieces[s]) - self.item_range[0]).contiguous()      # my rows the ranks want, by rank
         return plans
 
-    def step_planned(self, plan, slot=0):
-        """One global minibatch step from a plan of ``plan_steps``: no host synchronisation.  The batch's index sort
-        runs on the library's auxiliary stream beside the all-to-all that fetches the rows."""
+    def _prepare_planned(self, plan, slot):
+        """Index sort of a planned batch on the library's auxiliary stream (slot 0 or 1)."""
+        if plan["B"] > 0 and hasattr(self.backend, "prepare_batch") and not plan.get("prepared_in") == slot:
+            nu = self.user_range[1] - self.user_range[0]
+            self.backend.prepare_batch(slot, nu, sum(plan["send"]), plan["users"], plan["pos_slot"], plan["neg_slot"])
+            plan["prepared_in"] = slot
+
+    def step_planned(self, plan, slot=0, next_plan=None):
+        """One global minibatch step from a plan of ``plan_steps``: no host synchronisation, four exchanges (rows
+        and biases to the ranks that asked, gradient sums back).  The batch's index sort runs on the library's
+        auxiliary stream beside the exchange that fetches the rows; with ``next_plan`` the sort of the NEXT batch
+        is enqueued (other slot) before this step's gradient sums travel back, so that it runs beside them."""
         be, sc, rc = self.backend, plan["send"], plan["recv"]
-        B, n_uniq = plan["B"], sum(plan["send"])
-        nu = self.user_range[1] - self.user_range[0]
+        B = plan["B"]
         ahead = B > 0 and hasattr(be, "prepare_batch")
-        if ahead:
-            be.prepare_batch(slot, nu, n_uniq, plan["users"], plan["pos_slot"], plan["neg_slot"])
-        # (1) ids to their owners, (2) the owners' rows and biases back, in the order of plan["uniq"]
-        want = self._a2a(plan["uniq"], sc, rc)
-        local = (want - self.item_range[0]).contiguous()
+        self._prepare_planned(plan, slot)
+        tm = self._timers
+        if tm is not None:
+            tm.mark("start")
+        # (1) the owners' rows and biases to the ranks that asked for them, in the order of plan["uniq"] there
+        local = plan["local"]
         rows, bias = be.rows_gather(self.Q, self.b, local)
         Qc, bc = self._a2a(rows, rc, sc), self._a2a(bias, rc, sc)
-        # (3) local step: P shard updated in place, Qc / bc turned into gradient sums
+        if tm is not None:
+            tm.mark("fetch")
+        # (2) local step: P shard updated in place, Qc / bc turned into gradient sums
         if B > 0 and ahead and self._ut is not None:
             be.bpr_grad_step(self._P, Qc, bc, plan["users"], plan["pos_slot"], plan["neg_slot"], self.lr, self.reg, slot=slot, ut=self._ut)
             self._ut_dirty = True
         elif B > 0:
             be.bpr_grad_step(self.P, Qc, bc, plan["users"], plan["pos_slot"], plan["neg_slot"], self.lr, self.reg, slot=slot if ahead else -1)
-        # (4) gradient sums back to the owners, who add them in rank order and apply
+        if next_plan is not None:
+            self._prepare_planned(next_plan, slot ^ 1)
+        if tm is not None:
+            tm.mark("compute")
+        # (3) gradient sums back to the owners, who add them in rank order and apply
         gr, gb = self._a2a(Qc, sc, rc), self._a2a(bc, sc, rc)
+        if tm is not None:
+            tm.mark("return")
         if local.shape[0] > 0:
             be.rows_sgd_apply(self.Q, self.b, local, gr, gb, self.lr)
+        if tm is not None:
+            tm.mark("apply")
+
+    def run_planned(self, plans):
+        """The steps of ``plans`` in order, each batch's index sort enqueued one step ahead."""
+        for s, plan in enumerate(plans):
+            self.step_planned(plan, slot=s & 1, next_plan=plans[s + 1] if s + 1 < len(plans) else None)
 
     def full_item_table(self):
         """(Q, b) of ALL items on this rank: the local copy (replicated table) or an all-gather of the
@@ -594,13 +657,6 @@ class ShardedEvaluator:
             raise ValueError("user-sharded evaluation needs the replicated item table")
         self.layout = layout
 
-    def _gather_lists(self, x):
-        """[n, k] per rank -> [world, n, k] on every rank (800 bytes per user and rank at k=100)."""
-        t = self.t
-        if not t._coll:
-            return x.unsqueeze(0)
-        return torch.stack(_all_gather(x, t.world, t.group))
-
     def _evaluate_own_users(self):
         t, k = self.t, self.k
         sums = torch.zeros(5 * k, dtype=torch.float64, device=t.device)
@@ -621,28 +677,41 @@ class ShardedEvaluator:
         """float32 [5, k] on every rank: Precision, Recall, MAP, NDCG, MRR @1..k."""
         if self.layout == "users":
             return self._evaluate_own_users()
+        # Item-sharded.  A round takes the next ``chunk`` users of EVERY owner: their factor rows are all-gathered,
+        # every rank takes the top-k of all of the round's users over its own items, and one all-to-all sends each
+        # list to the owner of its user; all ranks then merge, fill and score their own users at the same time.
         t, k, W = self.t, self.k, self.t.world
         dev = t.device
         sums = torch.zeros(5 * k, dtype=torch.float64, device=dev)
         owners = torch.div(self.test_users.to(torch.int64), t.upr, rounding_mode="floor")
-        for o in range(W):
-            users_o = self.test_users[owners == o]
-            for s in range(0, users_o.shape[0], self.chunk):
-                eu = users_o[s:s + self.chunk].contiguous()
-                n = eu.shape[0]
-                if t.rank == o:
-                    rows = t.P.index_select(0, eu.to(torch.int64) - t.user_range[0]).contiguous()
-                else:
-                    rows = torch.empty((n, t.d), dtype=torch.float32, device=dev)
-                if t._coll:
-                    _broadcast(rows, o, t.group)
-                ids, sc = self.backend.score_topk_shard(rows, t.Q, t.b, t.item_range[0], eu, k, self.train, self.mode)
-                all_ids, all_sc = self._gather_lists(ids), self._gather_lists(sc)
-                if t.rank == o:        # the owner of the users merges, fills the masked tail and scores
-                    mi, _ = self.backend.topk_merge(all_ids.contiguous(), all_sc.contiguous(), W, n, k)
-                    if self.train is not None:
-                        self.backend.fill_masked(mi, eu, k, self.train)
-                    sums += self.backend.metric_sums(mi, eu, k, self.test)
+        by_owner = [self.test_users[owners == o] for o in range(W)]
+        longest = max(int(x.shape[0]) for x in by_owner) if W else 0
+        for s in range(0, longest, self.chunk):
+            parts = [x[s:s + self.chunk].contiguous() for x in by_owner]
+            sizes = [int(x.shape[0]) for x in parts]
+            mine = parts[t.rank]
+            rows_mine = t.P.index_select(0, mine.to(torch.int64) - t.user_range[0]).contiguous()
+            if t._coll and W > 1:
+                pad = torch.zeros((max(sizes), t.d), dtype=torch.float32, device=dev)
+                pad[: sizes[t.rank]] = rows_mine
+                rows = torch.cat([g[:n] for g, n in zip(_all_gather(pad, W, t.group), sizes)])
+            else:
+                rows = rows_mine
+            eu = torch.cat(parts).contiguous()
+            ids, sc = self.backend.score_topk_shard(rows, t.Q, t.b, t.item_range[0], eu, k, self.train, self.mode)
+            n_me = sizes[t.rank]
+            if t._coll and W > 1:
+                got_ids = torch.empty((W * n_me, k), dtype=ids.dtype, device=dev)
+                got_sc = torch.empty((W * n_me, k), dtype=sc.dtype, device=dev)
+                _all_to_all_rows(got_ids, ids, [n_me] * W, sizes, t.group)
+                _all_to_all_rows(got_sc, sc, [n_me] * W, sizes, t.group)
+            else:
+                got_ids, got_sc = ids, sc
+            if n_me > 0:
+                mi, _ = self.backend.topk_merge(got_ids.view(W, n_me, k).contiguous(), got_sc.view(W, n_me, k).contiguous(), W, n_me, k)
+                if self.train is not None:
+                    self.backend.fill_masked(mi, mine, k, self.train)
+                sums += self.backend.metric_sums(mi, mine, k, self.test)
         if t._coll:
             _all_reduce(sums, t.group)
         return (sums / float(self.test_users.shape[0])).to(torch.float32).reshape(5, k)
@@ -678,6 +747,20 @@ class ShardedEpochSampler:
         self.indices = torch.from_numpy(sub.indices.astype(np.int32)).to(dev)
         self.nnz = int(sub.nnz)
         self.n_neg, self.seed = int(n_neg), int(seed)
+
+    @classmethod
+    def from_local_csr(cls, dev_or_backend, trainer, indptr, indices, first, total_nnz, seed=2018, n_neg=1, shuffle="rank"):
+        """A sampler over this rank's rows given as device tensors (``indptr`` int64 [rows + 1] starting at 0,
+        ``indices`` int32, sorted within a row), for callers that build the interaction lists on the device;
+        ``first``: position of the rank's first interaction in the whole training set, ``total_nnz``: its size."""
+        self = cls.__new__(cls)
+        self.backend = dev_or_backend if hasattr(dev_or_backend, "uniform_rows") else HipBackend(dev_or_backend)
+        self.t, self.shuffle = trainer, shuffle
+        self.first, self.total_nnz = int(first), int(total_nnz)
+        self.indptr, self.indices = indptr, indices
+        self.nnz = int(indices.shape[0])
+        self.n_neg, self.seed = int(n_neg), int(seed)
+        return self
 
     def draw(self, e):
         """(local user rows, items, negatives) of epoch ``e`` in storage order; collective when the item
@@ -751,8 +834,7 @@ class ShardedEpochSampler:
                 t.step(*b, global_batch=size)
         elif t.item_mode == "sharded":
             # every message size of the epoch is settled here, in one exchange and one host read
-            for k, plan in enumerate(t.plan_steps(batches)):
-                t.step_planned(plan, slot=k & 1)
+            t.run_planned(t.plan_steps(batches))
         else:
             for b in batches:
                 t.step(*b)

@@ -36,17 +36,43 @@ def read_param_pickle_safely(path):
     payload_ops = ("BINBYTES", "SHORT_BINBYTES", "BINBYTES8", "BINSTRING", "SHORT_BINSTRING", "BINUNICODE", "SHORT_BINUNICODE",
                    "BINUNICODE8")
     int_ops = ("BININT", "BININT1", "BININT2", "LONG1", "INT")
+    # Protocols 4 and 5 name a global by the two texts on top of the stack before STACK_GLOBAL; either may come from
+    # the memo.  Enough of the machine is followed to know them: the texts pushed, the memo slots that hold texts.
+    top2, pushed, memo, n_memo = [], None, {}, 0
+    frombuffer = False      # the next bytes / bytearray operand is the buffer argument of numpy's _frombuffer
     for op, arg, _ in pickletools.genops(raw):
         name = op.name
-        if name in ("GLOBAL", "STACK_GLOBAL") and arg and not (str(arg).startswith("numpy") or str(arg) == "_codecs encode"):
-            raise ValueError("%s references %r: not a plain numpy parameter pickle" % (path, arg))
+        if name in ("BINUNICODE", "SHORT_BINUNICODE", "BINUNICODE8"):
+            pushed = str(arg)
+            top2 = (top2 + [pushed])[-2:]
+        elif name in ("BINGET", "LONG_BINGET"):
+            pushed = memo.get(int(arg))
+            if isinstance(pushed, tuple):            # a global fetched again (the second and third array reuse _frombuffer)
+                frombuffer = pushed[1].endswith(" _frombuffer")
+                top2 = []
+            else:
+                top2 = (top2 + [pushed])[-2:]
+        elif name == "MEMOIZE":
+            memo[n_memo] = pushed
+            n_memo += 1
+        elif name in ("BINPUT", "LONG_BINPUT"):
+            memo[int(arg)] = pushed
+        elif name != "STACK_GLOBAL":
+            top2, pushed = [], None
+        if name in ("GLOBAL", "STACK_GLOBAL"):
+            glob = str(arg) if name == "GLOBAL" else (" ".join(top2) if len(top2) == 2 and None not in top2 else "?")
+            top2, pushed = [], ("global", glob)
+            if not (glob.startswith("numpy") or glob == "_codecs encode"):
+                raise ValueError("%s references %r: not a plain numpy parameter pickle" % (path, glob))
+            frombuffer = glob.endswith(" _frombuffer")
         if expect_data and name in payload_ops:
             blobs.append((arg.encode("latin-1") if isinstance(arg, str) else bytes(arg), shape))
             expect_data = False
             continue
-        if name == "BYTEARRAY8":
+        # protocol 5: the array's buffer in band -- a bytearray when the array was writable, bytes when it was not
+        if name == "BYTEARRAY8" or (frombuffer and name in ("BINBYTES", "SHORT_BINBYTES", "BINBYTES8")):
             blobs.append((bytes(arg), None))
-            await_shape, run = True, []
+            await_shape, run, frombuffer = True, [], False
             continue
         if name in ("NEWFALSE", "NEWTRUE"):
             expect_data = True

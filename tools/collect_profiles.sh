@@ -21,3 +21,12 @@ timeout -s KILL 200 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $R/gp
 echo "eval pass 2 done"
 timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/gpurun_out/${TAG}_pmc_eval3 -- python3 $R/tools/eval_probe.py $EA > $R/gpurun_out/${TAG}_pmc_eval3.log 2>&1 || echo "eval pass 3 failed (counter names)"
 echo "eval pass 3 done"
+# the BPR step at the large configuration's table shape (10M users x 2M items, d=128, 4M triples, versioned table):
+# kernel durations and the two traffic counters, one pass each
+LA="--U 10000000 --I 2000000 --d 128 --batches 4194304 --versioned --steps 6 --plain-only"
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_large_stats -- python3 $R/tools/perf_probe.py $LA > $R/gpurun_out/${TAG}_large_stats.log 2>&1
+echo "large stats done"
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_large_fetch -- python3 $R/tools/perf_probe.py $LA > $R/gpurun_out/${TAG}_large_fetch.log 2>&1
+echo "large fetch done"
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_large_write -- python3 $R/tools/perf_probe.py $LA > $R/gpurun_out/${TAG}_large_write.log 2>&1
+echo "large write done"
