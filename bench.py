@@ -51,12 +51,13 @@ def zipf_items(n_items, size, gen, device, alpha=1.0):
     return out
 
 
-def pmc_traffic(B, d):
+def pmc_traffic(B, d, name="pmc_traffic.json"):
     """HBM bytes per step from the committed counter passes (profiles/pmc_traffic.json, written by
     tools/make_profile_summary.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same
-    workload); None when the file does not describe this batch size and factor size."""
+    workload; pmc_traffic_large.json: the same for the 10M-user x 2M-item shape); None when the file does not
+    describe this batch size and factor size."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", name)))
     except (OSError, ValueError):
         return None
     if t.get("workload_batch") != B or t.get("factors") != d:
@@ -206,7 +207,9 @@ def large_shape(dev, cuda, U=10_000_000, I=2_000_000, d=128, B=1 << 22, steps=10
     res = {"shape": "%d users x %d items, d=%d, %d triples per step, one GPU" % (U, I, d, B),
            "bpr_sgd_step": {"triples_per_s": B / (ms * 1e-3), "ms_per_step": ms, "user_table": "versioned",
                             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                         "algorithmic_bytes_per_triple": 24 * d + 28}}}
+                                         "algorithmic_bytes_per_triple": 24 * d + 28,
+                                         "traffic": pmc_traffic(B, d, "pmc_traffic_large.json") if (U, I) == (10_000_000, 2_000_000) else None,
+                                         "traffic_source": "profiles/pmc_traffic_large.json (committed rocprofv3 counter passes of this shape), not measured in this run"}}}
     del users, pos, neg
     oth = other_paths(dev, P, Q, b, U, I, d, B, g, cuda, steps=steps, epoch_pipeline=False)
     res.update(oth)

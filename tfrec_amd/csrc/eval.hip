@@ -825,7 +825,17 @@ __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk
             TF_PROF_ADD(3, prof_t_bar);
         } else if (TF_EVAL_ABLATE < 3) {
             [[maybe_unused]] const unsigned long long prof_t_bar = TF_PROF_T();
+#ifdef TF_EVAL_PROFILE
+            // (profile build: the wait for the staged tile's global loads, and the LDS stores, timed apart from the barrier)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            TF_PROF_ADD(15, prof_t_bar);
+            [[maybe_unused]] const unsigned long long prof_t_st = TF_PROF_T();
+#endif
             if (step + 1 < n_steps) store_tile(buf ^ 1);
+#ifdef TF_EVAL_PROFILE
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            TF_PROF_ADD(14, prof_t_st);
+#endif
             __syncthreads();
             TF_PROF_ADD(3, prof_t_bar);
         }

@@ -2,12 +2,12 @@
 # bench workload and of the scoring kernel, outputs under gpurun_out/ (TAG names the round, e.g. r2).
 set -e
 R=$GRAFT_REPO_ROOT
-TAG=${TAG:-r2}
+TAG=${TAG:-r3}
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 600 python3 $R/bench.py > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err
-echo "bench done"
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof_stats -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${TAG}_prof_stats.log 2>&1
-echo "stats done"
+# (part A, tools/collect_profiles_a.sh, runs the bench and its kernel statistics)
+
+
+
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-eval --no-cpu-baseline --no-other --no-extras > $R/gpurun_out/${TAG}_pmc_fetch.log 2>&1
 echo "fetch done"
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-eval --no-cpu-baseline --no-other --no-extras > $R/gpurun_out/${TAG}_pmc_write.log 2>&1

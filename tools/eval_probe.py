@@ -55,7 +55,7 @@ def main():
         if prof is not None:
             prof(buf, 1)
             w = max(buf[7], 1)
-            names = ["total", "filter+insert", "compaction", "store+barrier", "passing tiles", "compactions", "final", "waves", "c.fence", "c.load", "c.check", "c.descent", "c.write", "descent rounds", "id phases"]
+            names = ["total", "filter+insert", "compaction", "store+barrier", "passing tiles", "compactions", "final", "waves", "c.fence", "c.load", "c.check", "c.descent", "c.write", "descent rounds", "id phases / tile store", "tile load wait"]
             print("  per wave: " + ", ".join(f"{nm}={buf[i] / w:,.0f}" for i, nm in enumerate(names)), flush=True)
         print(f"eval {a.mode} {a.model}: {n} users x {a.I} items d={a.d} k={a.k}: {dt*1e3:.2f} ms  {n/dt:,.0f} users/s  {fl/1e12:.1f} TFLOP/s", flush=True)
 

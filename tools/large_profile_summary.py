@@ -61,6 +61,11 @@ def main():
             % ((tot_f + tot_w) / 1e6 / (tot_us * 1e-6), (tot_f + tot_w) / 1e6 / (tot_us * 1e-6) / 6.29),
             "would take %.2f ms, i.e. roofline.frac %.2f of 8 TB/s is the ceiling of this algorithm at this shape." % (
                 (tot_f + tot_w) / 1e6 / 6.29 * 1e-3 * 1e3, alg / 1e6 / ((tot_f + tot_w) / 1e6 / 6.29) / 8.0), ""]
+    import json
+    json.dump({"workload_batch": B, "factors": D, "users": 10_000_000, "items": 2_000_000, "bytes_per_step": (tot_f + tot_w) * 1e6,
+               "fetched_bytes_per_step": tot_f * 1e6, "written_bytes_per_step": tot_w * 1e6, "kernel_us_per_step": tot_us,
+               "source": "profiles/%s_large_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024)" % tag},
+              open(os.path.join(root, "profiles", "pmc_traffic_large.json"), "w"), indent=1)
     open(os.path.join(root, "profiles", tag + "_large_summary.md"), "w").write("\n".join(out) + "\n")
     print("\n".join(out))
 
