@@ -1,23 +1,24 @@
 // Full-rank evaluation: scoring of every (user, item) pair on the matrix cores with a running
 // top-k per user, top-k over dense rows, top-k merge, and the ranking metrics.
 //
-// score_topk_kernel never materialises the [users, items] score matrix that the reference
+// The scoring kernels never materialise the [users, items] score matrix that the reference
 // builds on the host (model/BPR.py:76-80) and masks in place
-// (evaluator/backend/cpp/evaluate.py:25-27).  A workgroup of four waves owns 128 users
-// (32 per wave, their factors resident in registers as the MFMA "B" operand) and streams
-// item tiles through LDS as the "A" operand:
+// (evaluator/backend/cpp/evaluate.py:25-27).  A wave owns 32 users (score_topk_kernel) or 64
+// (score_topk_pp_kernel: bf16, d = 128), their factors resident in registers as the MFMA "B"
+// operand, and the workgroup streams item tiles through LDS as the "A" operand:
 //     D[item][user] = bias[item] + sum_f Q[item][f] * P[user][f]
 //   * TFREC_SCORE_F32: v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain over f ascending that
 //     starts at the bias;
 //   * TFREC_SCORE_BF16: v_mfma_f32_32x32x16_bf16 on operands rounded to bfloat16.
 // In the accumulator layout a lane holds 16 items of ONE user, so one running threshold per
-// lane (the user's current k-th best score) filters the tile: a score above it is appended to
-// that user's candidate list.  When a list may overflow, the owning wave compacts it: drops
-// the user's train items (binary search in the sorted CSR row), bitonic-sorts the rest in LDS
-// under the total order (score descending, item id ascending) and keeps the best k, which
-// also tightens the threshold.  The reference's order among equal scores is whatever
-// std::partial_sort_copy leaves (evaluator/backend/cpp/tools.h:17); this order is the
-// documented replacement and makes item-sharded results merge exactly.
+// lane (a lower bound of the user's k-th best score so far) filters the tile: a score above it
+// is appended to that user's candidate list.  When a list may overflow, the owning wave compacts
+// it: drops the user's train items (binary search in the sorted CSR row), keeps the best k (or a
+// few more) by selection, which also tightens the threshold; the k survivors are sorted under the
+// total order (score descending, item id ascending) when the scan ends.  The reference's order
+// among equal scores is whatever std::partial_sort_copy leaves
+// (evaluator/backend/cpp/tools.h:17); this order is the documented replacement and makes
+// item-sharded results merge exactly.
 #include "common.hpp"
 
 #include <atomic>
@@ -26,6 +27,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------
 // keys: (score, id) packed so that a larger 64-bit key means "ranks earlier"
@@ -209,6 +211,50 @@ extern "C" int tfrec_debug_prof(unsigned long long *out, int reset)
 #define TF_PROF_ADD(i, t0) (void)(t0)
 #endif
 
+// Inclusive sum over the lanes 0..lane of a wave, by DPP row shifts and row broadcasts (six vector adds, no LDS trip).
+__device__ __forceinline__ int wave_prefix_sum(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
+// One level of a histogram selection among the keys a wave holds (EPL per lane).  A key takes part when its score bits from
+// `match_shift` up equal `match_value`; its bucket is the `nbits` (<= 6) bits from `shift` up.  Finds the highest bucket L
+// such that at least `want` taking-part keys lie in buckets >= L (the caller makes sure that `want` of them take part);
+// returns L, *above = keys in buckets > L, *in_bucket = keys in bucket L.  hist: 64 counters in LDS, this wave's own.
+// Wave-uniform arguments and results.
+template <int EPL>
+__device__ __forceinline__ int hist_select_level(const uint64_t (&keys)[EPL], int match_shift, uint32_t match_value, int shift, int nbits, int want,
+                                                 volatile uint32_t *hist, int lane, int *above, int *in_bucket)
+{
+    hist[lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t bmask = (1u << nbits) - 1u;
+#pragma unroll
+    for (int q = 0; q < EPL; ++q) {
+        const uint32_t hi = (uint32_t)(keys[q] >> 32);
+        if (keys[q] != 0 && (uint32_t)((uint64_t)hi >> match_shift) == match_value) atomicAdd(const_cast<uint32_t *>(hist) + ((hi >> shift) & bmask), 1u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int c = (int)hist[lane];
+    const int incl = wave_prefix_sum(c);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    const int at_or_above = total - incl + c;                     // keys in buckets >= lane
+    const uint64_t m = __ballot(at_or_above >= want);
+    const int L = m ? 63 - __builtin_clzll(m) : 0;
+    *in_bucket = __builtin_amdgcn_readlane(c, L);
+    *above = __builtin_amdgcn_readlane(at_or_above, L) - *in_bucket;
+    __builtin_amdgcn_wave_barrier();
+    return L;
+}
+
 // Compaction by selection: like wave_compact, but the k survivors are SELECTED, not sorted -- a list
 // only has to be in order when it is written out, and then only its k survivors (wave_finish).  The k-th largest key is found by descending over its
 // bits (one wave-uniform count per bit: compares, ballots and scalar population counts; the low
@@ -218,7 +264,11 @@ extern "C" int tfrec_debug_prof(unsigned long long *out, int reset)
 // its own region without asking the other): region r holds cnt_r entries, the first ver_r of them known not to be
 // masked.  INTERLEAVE: survivor j is written to region j & 1, slot j >> 1 (the list itself: both regions get half);
 // else to out[j] (the sort buffer of the final pass).
-template <int CAP, bool INTERLEAVE, class Out>
+// APPROX (compactions during the scan): the cut is found by two levels of a 64-way histogram over the score bits below the
+// highest bit in which the held scores differ, and is the lower edge of a bucket: at least k and in practice k or k + 1 keys
+// survive, *tau_out is a lower bound of the k-th best score -- all a filter threshold has to be.  When more than k + 16 keys
+// would survive (ties, or scores that differ only in their last bits), the exact descent runs instead.
+template <int CAP, bool INTERLEAVE, bool APPROX = false, class Out>
 __device__ __forceinline__ int wave_select(const uint64_t *list, int cnt0, int cnt1, int ver0, int ver1, int k,
                                            const int32_t *__restrict__ mask_idx, int64_t mlo, int64_t mhi,
                                            volatile uint64_t *sortbuf, int lane, float *tau_out, Out out,
@@ -320,6 +370,33 @@ __device__ __forceinline__ int wave_select(const uint64_t *list, int cnt0, int c
         all_or |= xor_lane_u32<2>(all_or, lane);   all_and &= xor_lane_u32<2>(all_and, lane);
         all_or |= xor_lane_u32<1>(all_or, lane);   all_and &= xor_lane_u32<1>(all_and, lane);
         const uint32_t differ = __builtin_amdgcn_readfirstlane(all_or ^ all_and);
+        bool cut_found = false;
+        if constexpr (APPROX) {
+            if (differ) {
+                volatile uint32_t *hist = reinterpret_cast<volatile uint32_t *>(sortbuf);     // the staged row is no longer needed
+                const int top = 31 - __builtin_clz(differ);
+                const uint32_t common = __builtin_amdgcn_readfirstlane(all_and);
+                // level 1: the six bits from the highest differing one down (every held key shares the bits above them)
+                const int shift1 = top >= 5 ? top - 5 : 0;
+                int above1, in1;
+                const int L1 = hist_select_level<EPL>(keys, shift1 + 6, (uint32_t)((uint64_t)common >> (shift1 + 6)), shift1, 6, k, hist, lane, &above1, &in1);
+                uint32_t hi_cut = (uint32_t)(((uint64_t)common >> (shift1 + 6)) << (shift1 + 6)) | ((uint32_t)L1 << shift1);
+                int survivors = above1 + in1;
+                if (survivors > k && shift1 > 0) {
+                    // level 2: the next (up to) six bits, among the keys of the level-1 bucket that holds the k-th
+                    const int shift2 = shift1 >= 6 ? shift1 - 6 : 0;
+                    int above2, in2;
+                    const int L2 = hist_select_level<EPL>(keys, shift1, hi_cut >> shift1, shift2, shift1 - shift2, k - above1, hist, lane, &above2, &in2);
+                    hi_cut |= (uint32_t)L2 << shift2;
+                    survivors = above1 + above2 + in2;
+                }
+                if (survivors <= k + 16) {
+                    cut = (uint64_t)hi_cut << 32;
+                    cut_found = true;
+                }
+            }
+        }
+        if (!cut_found) {
         // highest differing bit, moved up to an odd position so that whole pairs of bits remain (a shared
         // bit taken into the descent is simply found again)
         int bit = differ ? ((31 - __builtin_clz(differ)) | 1) : -1;
@@ -376,6 +453,7 @@ __device__ __forceinline__ int wave_select(const uint64_t *list, int cnt0, int c
                 }
             }
         }
+        }   // !cut_found
     }
 #ifdef TF_EVAL_PROFILE
     if (prof_acc) { prof_acc[11] += TF_PROF_T() - prof_t; prof_t = TF_PROF_T(); }
@@ -493,24 +571,6 @@ struct ScoreWave<256, true, CAP> { static constexpr int UW = 1, NW = 8; };
 template <int CAP>
 struct ScoreWave<64, false, CAP> { static constexpr int UW = 1, NW = 8; };
 
-// staging of item tiles in the sixteen-wave bf16 kernels: 1 = ring of short tiles with per-slot counters (see
-// ScoreGeom::RING), 0 = two long tiles and a workgroup barrier per tile
-#ifndef TF_EVAL_RING
-#define TF_EVAL_RING 0
-#endif
-#ifndef TF_EVAL_AFRAG_AHEAD
-#define TF_EVAL_AFRAG_AHEAD 0
-#endif
-#ifndef TF_EVAL_RING_TI
-#define TF_EVAL_RING_TI 64
-#endif
-#ifndef TF_EVAL_RING_SLOTS
-#define TF_EVAL_RING_SLOTS 6
-#endif
-#ifndef TF_EVAL_RING_AHEAD
-#define TF_EVAL_RING_AHEAD 3
-#endif
-
 // LDS bytes of an instantiation with tiles of `ti` items
 constexpr int score_lds_bytes(int ti, int rowb, int nw, int cap) { return 2 * ti * rowb + 2 * ti * 4 + nw * cap * 8 + 1536; }
 
@@ -522,32 +582,15 @@ struct ScoreGeom {
     // the barriers) where the CU's 160 KB hold two of them beside the sort buffers, else twice as long
     static constexpr int TI0 = D * ESZ >= 256 ? 64 : 128;
     static constexpr bool ALONE = ScoreWave<D, BF16, CAP>::NW == 16 || ScoreWave<D, BF16, CAP>::UW > 1;   // one workgroup per CU
-    static constexpr int TI_BARRIER = !ALONE ? TI0
+    static constexpr int TI = !ALONE ? TI0
                               : (score_lds_bytes(3 * TI0, ROWB, ScoreWave<D, BF16, CAP>::NW, CAP) <= 160 * 1024 &&
                                  (3 * TI0 * (D * ESZ / 16)) % (64 * ScoreWave<D, BF16, CAP>::NW) == 0 ? 3 * TI0 : 2 * TI0);
     static constexpr int CPR = D * ESZ / 16;                 // 16-byte chunks per row
     static constexpr int NW = ScoreWave<D, BF16, CAP>::NW, NT = 64 * NW;   // waves / threads per workgroup
-    // RING: the sixteen-wave bf16 instantiations stage item tiles through a ring of NSLOT short tiles guarded by
-    // per-slot counters in LDS instead of two long tiles and a workgroup barrier per tile: a wave that is held up
-    // (a compaction, a run of insertions) no longer stops the other fifteen at the next tile boundary; it may fall
-    // min(PF, NSLOT - PF) tiles behind before anybody waits for it (PF = how many tiles ahead a tile is staged).
-    static constexpr bool RING = TF_EVAL_RING != 0 && BF16 && ALONE && ScoreWave<D, BF16, CAP>::UW == 1;
-    static constexpr int TI = RING ? (TF_EVAL_RING_TI > NT / CPR ? TF_EVAL_RING_TI : NT / CPR) : TI_BARRIER;   // (at least a chunk per thread)
-    // as many slots as asked for and the LDS holds beside the sort buffers (at least three); a tile is staged half a ring ahead
-    static constexpr int ring_slots()
-    {
-        int n = TF_EVAL_RING_SLOTS;
-        while (n > 3 && n * (TI * ROWB + TI * 4) + NW * CAP * 8 + 1536 > 160 * 1024) --n;
-        return n;
-    }
-    static constexpr int NSLOT = RING ? ring_slots() : 2;
-    static constexpr int PF = !RING ? 1 : (NSLOT == TF_EVAL_RING_SLOTS ? TF_EVAL_RING_AHEAD : NSLOT / 2);
     static constexpr int NLD = TI * CPR / NT;                // chunks per thread per tile
     static_assert(NLD >= 1 && NLD * NT == TI * CPR && NT >= TI, "tile does not divide over the workgroup");
-    static_assert(!RING || (PF >= 1 && PF < NSLOT), "a tile is staged 1 .. NSLOT-1 tiles ahead");
     static constexpr int QBYTES = TI * ROWB;
-    static constexpr int LDS_BYTES = NSLOT * QBYTES + NSLOT * TI * 4 + NW * CAP * 8 + 1536;
-    static_assert(LDS_BYTES <= 160 * 1024, "the staging buffers do not fit the CU's LDS");
+    static constexpr int LDS_BYTES = 2 * QBYTES + 2 * TI * 4 + NW * CAP * 8 + 1536;
 };
 
 // Developer ablations of the scan loop (never defined in the shipped build): 1 = no list filter,
@@ -555,6 +598,10 @@ struct ScoreGeom {
 // per-tile maximum, 6 = 5 with the matrix work issued as 16x16x32 instructions (bf16; a clock comparison).
 #ifndef TF_EVAL_ABLATE
 #define TF_EVAL_ABLATE 0
+#endif
+// compactions during the scan cut by histogram (see wave_select); 0 = by the exact descent
+#ifndef TF_EVAL_APPROX_SELECT
+#define TF_EVAL_APPROX_SELECT 1
 #endif
 
 template <int D, bool BF16, int CAP>
@@ -564,14 +611,9 @@ __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk
     constexpr int TI = G::TI, ROWB = G::ROWB, CPR = G::CPR, NLD = G::NLD, ESZ = G::ESZ;
     constexpr int UW = ScoreWave<D, BF16, CAP>::UW, NT = G::NT, UB = 32 * G::NW * UW;   // user sets per wave, threads and users per workgroup
     extern __shared__ __align__(16) char lds[];
-    constexpr bool RING = G::RING;
-    constexpr int NSLOT = G::NSLOT, PF = G::PF;
-    char *qbuf = lds;                                                   // [NSLOT][TI*ROWB]
-    float *bias = reinterpret_cast<float *>(lds + NSLOT * G::QBYTES);    // [NSLOT][TI]
-    uint64_t *sortbuf = reinterpret_cast<uint64_t *>(bias + NSLOT * TI); // [waves][CAP]
-    // ring: per slot, how many waves have stored their share of a tile (ready) and how many have finished reading
-    // one (done); the counts only grow, a slot's n-th use waits for n * waves
-    uint32_t *ring_ready = reinterpret_cast<uint32_t *>(sortbuf + G::NW * CAP), *ring_done = ring_ready + NSLOT;
+    char *qbuf = lds;                                                   // [2][TI*ROWB]
+    float *bias = reinterpret_cast<float *>(lds + 2 * G::QBYTES);        // [2][TI]
+    uint64_t *sortbuf = reinterpret_cast<uint64_t *>(bias + 2 * TI);     // [waves][CAP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int uj = lane & 31, h = lane >> 5;
@@ -654,40 +696,13 @@ __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk
     volatile uint64_t *mysort = sortbuf + wave * CAP;
     const int lane_row_off = uj * ROWB, lane_bias_off = 4 * h;     // this lane's place in an LDS tile
 
+    load_tile(it0);
+    store_tile(0);
+    __syncthreads();
     const int64_t n_steps = (it1 - it0 + TI - 1) / TI;
-    auto ring_signal = [&](uint32_t *c) {
-        // (a wave's LDS operations execute in order: the count moves after the wave's own stores / reads of the slot)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    auto ring_wait = [&](uint32_t *c, uint32_t target) {
-        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
-            __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    };
-    if constexpr (RING) {
-        if (tid < 2 * NSLOT) ring_ready[tid] = 0;
-        __syncthreads();
-        for (int p = 0; p < PF && p < n_steps; ++p) {       // the first PF tiles: their slots are fresh
-            load_tile(it0 + (int64_t)p * TI);
-            store_tile(p);
-            ring_signal(&ring_ready[p]);
-        }
-    } else {
-        load_tile(it0);
-        store_tile(0);
-        __syncthreads();
-    }
-    int ring_slot = 0, ring_nslot = PF % NSLOT;             // slot of this step's tile, slot of the tile staged during it
-    uint32_t ring_use = 1, ring_nuse = PF / NSLOT;           // ordinal of this step's use of its slot; completed uses of the other
     for (int64_t step = 0; step < n_steps; ++step) {
-        const int buf = RING ? ring_slot : (int)(step & 1);
-        if constexpr (RING) {
-            if (step + PF < n_steps) load_tile(it0 + (step + PF) * TI);
-            ring_wait(&ring_ready[buf], (uint32_t)G::NW * ring_use);
-        } else {
-            if (TF_EVAL_ABLATE < 3 && step + 1 < n_steps) load_tile(it0 + (step + 1) * TI);
-        }
+        const int buf = (int)(step & 1);
+        if (TF_EVAL_ABLATE < 3 && step + 1 < n_steps) load_tile(it0 + (step + 1) * TI);
         const char *qb = qbuf + buf * G::QBYTES;
         const float *bb = bias + buf * TI;
 #pragma unroll 1
@@ -703,21 +718,9 @@ __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk
             }
             const char *arow = qb + lane_row_off + sb * (32 * ROWB);
             if constexpr (BF16) {
-#if TF_EVAL_AFRAG_AHEAD
-                // all of the block's A fragments requested before the first matrix instruction: one LDS round trip per
-                // block of 32 items instead of one per pair of fragments
-                bf16x8 avs[D / 16];
-#pragma unroll
-                for (int ks = 0; ks < D / 16; ++ks) avs[ks] = *reinterpret_cast<const bf16x8 *>(arow + (16 * ks + 8 * h) * 2);
-                __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
                 for (int ks = 0; ks < D / 16; ++ks) {
-#if TF_EVAL_AFRAG_AHEAD
-                    const bf16x8 av = avs[ks];
-#else
                     const bf16x8 av = TF_EVAL_ABLATE >= 2 ? pb[0][ks] : *reinterpret_cast<const bf16x8 *>(arow + (16 * ks + 8 * h) * 2);
-#endif
 #if TF_EVAL_ABLATE >= 6
                     {   // timing only: the same flops as two 16x16x32 instructions (results meaningless)
                         typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -801,7 +804,7 @@ __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk
                     // mid-scan compaction; the threshold is a few ranks looser.)
                     const int64_t L = shi - slo;
                     const bool defer = a.train_indices != nullptr && a.k + L <= CAP / 2;
-                    const int nc = wave_select<CAP, true>(sl, __builtin_amdgcn_readlane(mycnt[s], src), __builtin_amdgcn_readlane(mycnt[s], src + 32),
+                    const int nc = wave_select<CAP, true, TF_EVAL_APPROX_SELECT != 0>(sl, __builtin_amdgcn_readlane(mycnt[s], src), __builtin_amdgcn_readlane(mycnt[s], src + 32),
                                                           __builtin_amdgcn_readlane(myver[s], src), __builtin_amdgcn_readlane(myver[s], src + 32),
                                                           defer ? a.k + (int)L : a.k, defer ? nullptr : a.train_indices, slo, shi, mysort, lane,
                                                           &nt, sl, prof_acc);
@@ -811,31 +814,9 @@ __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk
                 TF_PROF_ADD(2, prof_t_cmp);
             }
         }
-        if constexpr (RING) {
+        if (TF_EVAL_ABLATE < 3) {
             [[maybe_unused]] const unsigned long long prof_t_bar = TF_PROF_T();
-            ring_signal(&ring_done[buf]);
-            if (step + PF < n_steps) {
-                // the slot's previous tile (NSLOT tiles before the one staged now) must have been read by every wave
-                ring_wait(&ring_done[ring_nslot], (uint32_t)G::NW * ring_nuse);
-                store_tile(ring_nslot);
-                ring_signal(&ring_ready[ring_nslot]);
-            }
-            if (++ring_slot == NSLOT) { ring_slot = 0; ++ring_use; }
-            if (++ring_nslot == NSLOT) { ring_nslot = 0; ++ring_nuse; }
-            TF_PROF_ADD(3, prof_t_bar);
-        } else if (TF_EVAL_ABLATE < 3) {
-            [[maybe_unused]] const unsigned long long prof_t_bar = TF_PROF_T();
-#ifdef TF_EVAL_PROFILE
-            // (profile build: the wait for the staged tile's global loads, and the LDS stores, timed apart from the barrier)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            TF_PROF_ADD(15, prof_t_bar);
-            [[maybe_unused]] const unsigned long long prof_t_st = TF_PROF_T();
-#endif
             if (step + 1 < n_steps) store_tile(buf ^ 1);
-#ifdef TF_EVAL_PROFILE
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            TF_PROF_ADD(14, prof_t_st);
-#endif
             __syncthreads();
             TF_PROF_ADD(3, prof_t_bar);
         }
@@ -851,6 +832,311 @@ __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk
             if (sur >= a.n) break;     // wave-uniform
             uint64_t *sl = a.lists + ((size_t)blockIdx.y * a.n + sur) * CAP;
             const int64_t slo = __shfl(mlo[s], src, 64), shi = __shfl(mhi[s], src, 64);
+            const int nc = wave_finish<CAP>(sl, __builtin_amdgcn_readlane(mycnt[s], src), __builtin_amdgcn_readlane(mycnt[s], src + 32),
+                                            __builtin_amdgcn_readlane(myver[s], src), __builtin_amdgcn_readlane(myver[s], src + 32), a.k,
+                                            a.train_indices, slo, shi, mysort, lane);
+            int32_t *oi = a.out_ids + ((size_t)blockIdx.y * a.n + sur) * a.k;
+            float *os = a.out_scores + ((size_t)blockIdx.y * a.n + sur) * a.k;
+            for (int e = lane; e < a.k; e += 64) {
+                const uint64_t key = e < nc ? mysort[e] : 0;
+                oi[e] = e < nc ? key_id(key) : -1;
+                os[e] = e < nc ? key_score(key) : -INFINITY;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+#ifdef TF_EVAL_PROFILE
+    TF_PROF_ADD(6, prof_t_fin);
+    TF_PROF_ADD(0, prof_t_start);
+    if (lane == 0)
+        for (int i = 0; i < 16; ++i) if (i != 7) atomicAdd(&tf_prof[i], prof_acc[i]);
+    if (lane == 0) atomicAdd(&tf_prof[7], 1ull);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
+// bf16 scoring, d = 128, with 64 users per wave
+//
+// score_topk_kernel with sixteen waves of 32 users reads one kilobyte of A fragment from LDS per matrix instruction,
+// which for the four SIMDs of a CU is the 128 bytes per clock the LDS delivers: the LDS, not the matrix pipe, paces
+// that scan, and a wave's filter work sits between its matrix instructions.  Here a wave owns 64 users (two B-operand
+// sets, every A fragment feeds two matrix instructions), a workgroup is eight waves (two per SIMD, up to 256 registers
+// each), and the instruction stream of ONE wave keeps the matrix pipe fed by itself:
+//     phase A of a block of 32 items: the 8 matrix instructions of user set 0, and between them the group maxima of
+//                                     set 1's scores of the block before;
+//     phase B:                        the 8 matrix instructions of set 1, between them the group maxima of set 0's
+//                                     scores of this block and the LDS reads of the next block's A fragments (each
+//                                     fragment register is refilled right after its last use) and biases.
+// A SIMD issues about five vector instructions per matrix instruction without delaying the matrix pipe, so as long as no
+// score passes its user's threshold the matrix instructions of consecutive blocks follow each other without a gap.
+// Only a passing score leaves that stream (appends, compactions: the epilogue of score_topk_kernel), and then the
+// other wave of the SIMD has the pipe.  Results are those of score_topk_kernel<128, true, CAP> exactly: the same
+// products in the same order per score, the same filter, the same selection.
+// ------------------------------------------------------------------------------------------
+#ifndef TF_EVAL_PP
+#define TF_EVAL_PP 1
+#endif
+#ifndef TF_EVAL_PP_TI
+#define TF_EVAL_PP_TI 256
+#endif
+// developer ablation (never defined in the shipped build): 1 = no score passes the filter
+#ifndef TF_EVAL_PP_ABLATE
+#define TF_EVAL_PP_ABLATE 0
+#endif
+template <int D, int CAP>
+struct PpGeom {
+    static constexpr int UW = 2, NW = 8, NT = 64 * NW, UB = 32 * NW * UW;   // user sets per wave, waves, threads, users per workgroup
+    static constexpr int KS = D / 16;                        // matrix instructions per set and block
+    static constexpr int ROWB = D * 2 + 16, CPR = D * 2 / 16;
+    static constexpr int TI = CAP <= 256 ? TF_EVAL_PP_TI : 192, NB = TI / 32;   // items and blocks per tile (as many as fit beside the sort buffers)
+    static constexpr int NLD = TI * CPR / NT;
+    static_assert(KS == 8, "the interleaving below is written for eight matrix instructions per phase");
+    static_assert(NB >= 2 && NLD >= 1 && NLD * NT == TI * CPR && NT >= TI, "tile does not divide over the workgroup");
+    static constexpr int QBYTES = TI * ROWB;
+    static constexpr int LDS_BYTES = score_lds_bytes(TI, ROWB, NW, CAP);
+    // the fragment refills of a tile's last block read one block past the tile (discarded): still inside the allocation
+    static_assert(LDS_BYTES <= 160 * 1024 && 32 * ROWB <= 2 * TI * 4 + NW * CAP * 8, "tile buffers and sort buffers exceed the CU's LDS");
+};
+
+// a pointer to global memory that is the same in every lane, moved into scalar registers (the result keeps the global
+// address space, so that loads through it take the form scalar base + 32-bit lane offset)
+template <class T>
+using global_ptr = __attribute__((address_space(1))) T *;
+template <class T>
+__device__ __forceinline__ global_ptr<const T> uniform_global(const T *p)
+{
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return (global_ptr<const T>)(((uint64_t)hi << 32) | lo);
+}
+
+template <int D, int CAP>
+__global__ __launch_bounds__(512) void score_topk_pp_kernel(ScoreArgs a)
+{
+    using G = PpGeom<D, CAP>;
+    constexpr int TI = G::TI, ROWB = G::ROWB, CPR = G::CPR, NLD = G::NLD, NB = G::NB, KS = G::KS, UW = G::UW, NT = G::NT;
+    extern __shared__ __align__(16) char lds[];
+    char *qbuf = lds;                                                   // [2][TI*ROWB]
+    float *bias = reinterpret_cast<float *>(lds + 2 * G::QBYTES);        // [2][TI]
+    uint64_t *sortbuf = reinterpret_cast<uint64_t *>(bias + 2 * TI);     // [waves][CAP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int uj = lane & 31, h = lane >> 5;
+    [[maybe_unused]] unsigned long long prof_acc[16] = {};
+    [[maybe_unused]] const unsigned long long prof_t_start = TF_PROF_T();
+    const int64_t wave_user0 = (int64_t)blockIdx.x * G::UB + wave * 32 * UW;
+    const int64_t it0 = (int64_t)blockIdx.y * a.split_items;
+    const int64_t it1 = it0 + a.split_items < a.n_items ? it0 + a.split_items : a.n_items;
+
+    // per user set, as in score_topk_kernel: the lane's half of its user's candidate list, its counts, the threshold
+    // (the user's train row is looked up when a compaction needs it, not held)
+    uint64_t *mylist[UW];
+    int32_t myuser[UW];
+    int mycnt[UW], myver[UW];
+    float th[UW];
+    bf16x8 pb[UW][KS];
+#pragma unroll
+    for (int s = 0; s < UW; ++s) {
+        const int64_t ur = wave_user0 + s * 32 + uj;
+        const bool uvalid = ur < a.n;
+        const int64_t urc = uvalid ? ur : a.n - 1;
+        myuser[s] = a.users[urc];
+        mylist[s] = a.lists + ((size_t)blockIdx.y * a.n + urc) * CAP + h * (CAP / 2);
+        mycnt[s] = 0; myver[s] = 0;
+        th[s] = uvalid && TF_EVAL_PP_ABLATE == 0 ? -INFINITY : INFINITY;
+        const float *prow = a.P + (size_t)(a.p_compact ? urc : (int64_t)myuser[s]) * a.d;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int f = 16 * ks + 8 * h + j;
+                v[j] = (__bf16)(f < a.d ? prow[f] : 0.f);
+            }
+            pb[s][ks] = v;
+        }
+    }
+
+    // staging of a tile through registers: thread t moves the 16-byte chunks t, t + NT, ... of the tile (chunk c = row
+    // c / CPR, column c % CPR).  Addresses are one uniform base per tile plus a per-thread 32-bit offset, so that no
+    // per-chunk address has to live in a register across the scan.
+    u32x4 stg[NLD];
+    float bstg = 0.f;
+    const uint32_t stg_off = (uint32_t)tid * 16u;
+    auto load_tile = [&](int64_t item_base) {
+        // both bases are made scalar registers here, per tile (else their per-thread sums are hoisted out of the scan
+        // and live in vector registers, or in scratch, for all of it)
+        const global_ptr<const char> tb = uniform_global(reinterpret_cast<const char *>(a.Qt) + (size_t)item_base * (D * 2));
+        const global_ptr<const float> bb = uniform_global(a.b + (a.item_lo + item_base));
+        // (rows past the end of the range carry a bias of -inf, which keeps them out of every list)
+        if (tid < TI) bstg = item_base + tid < it1 ? bb[tid] : -INFINITY;
+        if (item_base + TI <= it1) {
+#pragma unroll
+            for (int m = 0; m < NLD; ++m) stg[m] = *(global_ptr<const u32x4>)(tb + (stg_off + (uint32_t)(m * NT * 16)));
+        } else {
+            // the last tile of the range: rows past its end are zero
+#pragma unroll
+            for (int m = 0; m < NLD; ++m) {
+                const int64_t it = item_base + (tid + NT * m) / CPR;
+                stg[m] = it < it1 ? *(global_ptr<const u32x4>)(tb + (stg_off + (uint32_t)(m * NT * 16))) : u32x4{0, 0, 0, 0};
+            }
+        }
+    };
+    const int stg_lds = (tid / CPR) * ROWB + (tid % CPR) * 16;
+    auto store_tile = [&](int buf) {
+        char *to = qbuf + buf * G::QBYTES + stg_lds;
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) *reinterpret_cast<u32x4 *>(to + m * (NT / CPR) * ROWB) = stg[m];
+        if (tid < TI) bias[buf * TI + tid] = bstg;
+    };
+
+    volatile uint64_t *mysort = sortbuf + wave * CAP;
+    const int lane_row_off = uj * ROWB + 16 * h, lane_bias_off = 4 * h;
+
+    bf16x8 af[KS];            // A fragments of the block whose matrix instructions come next
+    f32x16 bv;                // its biases: the accumulators' starting value
+    f32x16 acc[UW];
+    auto read_bias = [&](f32x16 &to, const float *bb) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 v = *reinterpret_cast<const float4 *>(bb + 8 * g);
+            to[4 * g + 0] = v.x; to[4 * g + 1] = v.y; to[4 * g + 2] = v.z; to[4 * g + 3] = v.w;
+        }
+    };
+    auto group_max = [&](const f32x16 &x, int g) { return fmaxf(fmaxf(x[4 * g], x[4 * g + 1]), fmaxf(x[4 * g + 2], x[4 * g + 3])); };
+    // Scores of block nb of user set S passed their thresholds (gm: the lane's maxima over groups of four): appends, and
+    // compaction of every list that could overflow during the next block -- the epilogue of score_topk_kernel.
+    auto insert = [&]<int S>(int64_t nb, const float (&gm)[4]) {
+        [[maybe_unused]] const unsigned long long prof_t_ins = TF_PROF_T();
+        prof_acc[4] += 1;
+        const int32_t id0 = (int32_t)(a.id_offset + a.item_lo + it0 + nb * 32 + 4 * h);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (__ballot(gm[g] > th[S]) != 0) {
+#pragma unroll
+                for (int r = 4 * g; r < 4 * g + 4; ++r) {
+                    if (acc[S][r] > th[S]) {        // per lane: an append asks nobody
+                        mylist[S][mycnt[S]] = make_key(acc[S][r], id0 + (r & 3) + 8 * (r >> 2));
+                        mycnt[S] += 1;
+                    }
+                }
+            }
+        }
+        uint64_t need = __ballot(mycnt[S] > CAP / 2 - 16);
+        need = (need | (need >> 32)) & 0xffffffffull;          // by user
+        TF_PROF_ADD(14, prof_t_ins);
+        [[maybe_unused]] const unsigned long long prof_t_cmp = TF_PROF_T();
+        while (need) {
+            prof_acc[5] += 1;
+            const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(need));
+            need &= need - 1;
+            const int64_t sur = wave_user0 + S * 32 + src;
+            uint64_t *sl = a.lists + ((size_t)blockIdx.y * a.n + sur) * CAP;
+            const int32_t su = __builtin_amdgcn_readlane(myuser[S], src);
+            const int64_t slo = a.train_indptr ? a.train_indptr[su] : 0, shi = a.train_indptr ? a.train_indptr[su + 1] : 0;
+            float nt;
+            // few train items: not checked during the scan (see score_topk_kernel)
+            const int64_t L = shi - slo;
+            const bool defer = a.train_indices != nullptr && a.k + L <= CAP / 2;
+            const int nc = wave_select<CAP, true, TF_EVAL_APPROX_SELECT != 0>(sl, __builtin_amdgcn_readlane(mycnt[S], src), __builtin_amdgcn_readlane(mycnt[S], src + 32),
+                                                  __builtin_amdgcn_readlane(myver[S], src), __builtin_amdgcn_readlane(myver[S], src + 32),
+                                                  defer ? a.k + (int)L : a.k, defer ? nullptr : a.train_indices, slo, shi, mysort, lane,
+                                                  &nt, sl, prof_acc);
+            if (uj == src) { mycnt[S] = (nc + 1 - h) >> 1; myver[S] = defer ? 0 : mycnt[S]; th[S] = nt; }
+            // vmcnt(0) lgkmcnt(0): no load of the compaction is left "possibly pending" where the scan resumes (the compiler
+            // would otherwise guard the scan's registers with waits that also wait for the next tile's global loads, and wait
+            // for all of a block's fragment reads where the first would do)
+            __builtin_amdgcn_s_waitcnt(0x0070);
+        }
+        TF_PROF_ADD(15, prof_t_cmp);
+    };
+
+    const int64_t n_tiles = (it1 - it0 + TI - 1) / TI;
+    load_tile(it0);
+    store_tile(0);
+    // A tile's global loads are issued just before the barrier that ends the tile before the one they are stored in:
+    // the wave that reaches a barrier first (the one the SIMD's arbiter favours) has them back when the barrier opens,
+    // and the other one waits its turn for the matrix pipe anyway.
+    if (n_tiles > 1) load_tile(it0 + TI);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[1][j] = -INFINITY;      // "the block before the first": nothing passes
+    float gm0[4], gm1[4], mx0 = -INFINITY, mx1 = -INFINITY;
+#pragma unroll 1
+    for (int64_t tile = 0; tile < n_tiles; ++tile) {
+        const int buf = (int)(tile & 1);
+        {
+            // in the order the scan requests them (fragments 0 and 1, biases, the other fragments), so that the first
+            // matrix instruction of a block waits for what it needs and no more, wherever the block was entered from
+            const char *arow = qbuf + buf * G::QBYTES + lane_row_off;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                af[ks] = *reinterpret_cast<const bf16x8 *>(arow + 32 * ks);
+                if (ks == 1) read_bias(bv, bias + buf * TI + lane_bias_off);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        [[maybe_unused]] const unsigned long long prof_t_blk = TF_PROF_T();
+#pragma unroll 1
+        for (int sb = 0; sb < NB; ++sb) {
+            const int64_t nb = tile * NB + sb;
+            const char *arow_next = qbuf + buf * G::QBYTES + (sb + 1) * (32 * ROWB) + lane_row_off;   // past the tile for its last block
+            const float *bias_next = bias + buf * TI + (sb + 1) * 32 + lane_bias_off;
+            // ---- phase A: set 0 of block nb; maxima of set 1 of block nb - 1
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], pb[0][ks], ks == 0 ? bv : acc[0], 0, 0, 0);
+                if (ks >= 1 && ks <= 4) gm1[ks - 1] = group_max(acc[1], ks - 1);
+                if (ks == 5) mx1 = fmaxf(fmaxf(gm1[0], gm1[1]), fmaxf(gm1[2], gm1[3]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (__ballot(mx1 > th[1]) != 0) insert.template operator()<1>(nb - 1, gm1);
+            // ---- phase B: set 1 of block nb; maxima of set 0 of block nb; operands of block nb + 1
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], pb[1][ks], ks == 0 ? bv : acc[1], 0, 0, 0);
+                // the biases keep registers of their own up to here (else the accumulator is built in theirs and copied out
+                // when they are read again); then the next block's are requested
+                if (ks == 0) asm volatile("" ::"v"(bv));
+                af[ks] = *reinterpret_cast<const bf16x8 *>(arow_next + 32 * ks);
+                if (ks == 1) read_bias(bv, bias_next);
+                if (ks >= 2 && ks <= 5) gm0[ks - 2] = group_max(acc[0], ks - 2);
+                if (ks == 6) mx0 = fmaxf(fmaxf(gm0[0], gm0[1]), fmaxf(gm0[2], gm0[3]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (__ballot(mx0 > th[0]) != 0) insert.template operator()<0>(nb, gm0);
+        }
+        TF_PROF_ADD(1, prof_t_blk);
+        // the next tile: this thread's part into the other buffer, visible to all after the barrier
+        [[maybe_unused]] const unsigned long long prof_t_bar = TF_PROF_T();
+        if (tile + 1 < n_tiles) store_tile(buf ^ 1);
+        if (tile + 2 < n_tiles) load_tile(it0 + (tile + 2) * TI);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        TF_PROF_ADD(2, prof_t_bar);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        TF_PROF_ADD(3, prof_t_bar);
+    }
+    // set 1 of the last block
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gm1[g] = group_max(acc[1], g);
+    mx1 = fmaxf(fmaxf(gm1[0], gm1[1]), fmaxf(gm1[2], gm1[3]));
+    if (__ballot(mx1 > th[1]) != 0) insert.template operator()<1>(n_tiles * NB - 1, gm1);
+    [[maybe_unused]] const unsigned long long prof_t_fin = TF_PROF_T();
+
+    // final compaction and output: the wave's users one after the other
+#pragma unroll
+    for (int s = 0; s < UW; ++s) {
+        for (int src = 0; src < 32; ++src) {
+            const int64_t sur = wave_user0 + s * 32 + src;
+            if (sur >= a.n) break;     // wave-uniform
+            uint64_t *sl = a.lists + ((size_t)blockIdx.y * a.n + sur) * CAP;
+            const int32_t su = __builtin_amdgcn_readlane(myuser[s], src);
+            const int64_t slo = a.train_indptr ? a.train_indptr[su] : 0, shi = a.train_indptr ? a.train_indptr[su + 1] : 0;
             const int nc = wave_finish<CAP>(sl, __builtin_amdgcn_readlane(mycnt[s], src), __builtin_amdgcn_readlane(mycnt[s], src + 32),
                                             __builtin_amdgcn_readlane(myver[s], src), __builtin_amdgcn_readlane(myver[s], src + 32), a.k,
                                             a.train_indices, slo, shi, mysort, lane);
@@ -1124,16 +1410,31 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const double *__restr
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-static int cap_for_k(int k) { return k <= 112 ? 256 : (k <= 240 ? 512 : 0); }
+#ifndef TF_EVAL_CAP256_MAXK
+#define TF_EVAL_CAP256_MAXK 112
+#endif
+static int cap_for_k(int k) { return k <= TF_EVAL_CAP256_MAXK ? 256 : (k <= 240 ? 512 : 0); }
 
 template <int D, bool BF16, int CAP>
 static int launch_score(tfrec_ctx *ctx, const ScoreArgs &a, int user_blocks, int splits)
 {
-    using G = ScoreGeom<D, BF16, CAP>;
     // the dynamic-LDS limit is a per-device attribute of the kernel: set once on every device this
     // instantiation runs on (bit = device ordinal; devices beyond 63 set it on every launch)
     static std::atomic<uint64_t> attr_devices{0};
     const uint64_t dev_bit = ctx->device < 64 ? (1ull << ctx->device) : 0ull;
+    if constexpr (TF_EVAL_PP && BF16 && D == 128) {
+        using PG = PpGeom<D, CAP>;
+        if (!(attr_devices.load(std::memory_order_acquire) & dev_bit)) {
+            TF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&score_topk_pp_kernel<D, CAP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PG::LDS_BYTES));
+            attr_devices.fetch_or(dev_bit, std::memory_order_release);
+        }
+        user_blocks = (int)((a.n + PG::UB - 1) / PG::UB);
+        score_topk_pp_kernel<D, CAP><<<dim3(user_blocks, splits), PG::NT, PG::LDS_BYTES, ctx->stream>>>(a);
+        TF_HIP(hipGetLastError());
+        return TFREC_OK;
+    }
+    using G = ScoreGeom<D, BF16, CAP>;
     if (!(attr_devices.load(std::memory_order_acquire) & dev_bit)) {
         TF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&score_topk_kernel<D, BF16, CAP>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
@@ -1223,7 +1524,7 @@ static int plan_score(const float *d_Q, int d, int64_t item_lo, int64_t item_hi,
     p->TI = 768;      // a multiple of every ScoreGeom::TI
     p->chunk = 1 << 20;          // users per launch: bounds the candidate-list workspace
     // waves per workgroup of the instantiation that will run (ScoreWave<D, BF16, CAP>::NW)
-    const int nw = p->bf16 ? (p->D == 64 ? 16 : (p->D == 128 ? (p->CAP <= 256 ? 16 : 8) : (p->D == 256 ? 8 : 4))) : (p->D == 64 ? 8 : 4);
+    const int nw = p->bf16 ? (p->D == 64 ? 16 : (p->D == 128 ? (TF_EVAL_PP || p->CAP <= 256 ? 16 : 8) : (p->D == 256 ? 8 : 4))) : (p->D == 64 ? 8 : 4);
     const int64_t ub = 32 * nw;                    // users per workgroup
     const int64_t user_blocks_all = (n + ub - 1) / ub;
     const int64_t want_blocks = 512 * 4 / nw > 256 ? 512 * 4 / nw : 256;     // 2048 waves, and no CU left without a workgroup

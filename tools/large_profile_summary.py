@@ -60,7 +60,7 @@ def main():
             "Moved bytes / kernel time = %.2f TB/s = %.2f of the 6.29 TB/s a streaming copy reaches; at that copy rate the moved bytes alone"
             % ((tot_f + tot_w) / 1e6 / (tot_us * 1e-6), (tot_f + tot_w) / 1e6 / (tot_us * 1e-6) / 6.29),
             "would take %.2f ms, i.e. roofline.frac %.2f of 8 TB/s is the ceiling of this algorithm at this shape." % (
-                (tot_f + tot_w) / 1e6 / 6.29 * 1e-3 * 1e3, alg / 1e6 / ((tot_f + tot_w) / 1e6 / 6.29) / 8.0), ""]
+                (tot_f + tot_w) / 1e6 / 6.29 * 1e3, alg / 1e6 / ((tot_f + tot_w) / 1e6 / 6.29) / 8.0), ""]
     import json
     json.dump({"workload_batch": B, "factors": D, "users": 10_000_000, "items": 2_000_000, "bytes_per_step": (tot_f + tot_w) * 1e6,
                "fetched_bytes_per_step": tot_f * 1e6, "written_bytes_per_step": tot_w * 1e6, "kernel_us_per_step": tot_us,
