@@ -36,6 +36,19 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
 
 
+def _sustained_bf16():
+    """TFLOP/s that v_mfma_f32_32x32x16_bf16 sustained on random operands in tools/mfma_rate.hip (profiles/mfma_rate.json;
+    measured once, not in the run: it takes a second of the whole chip)."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "mfma_rate.json")) as f:
+            return float(json.load(f)["sustained_bf16_32x32x16_random_tflops"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+SUSTAINED_BF16_TFLOPS = _sustained_bf16()
+
+
 def zipf_items(n_items, size, gen, device, alpha=1.0):
     """Items ~ Zipf(alpha) over a random permutation of the ids (hot rows exist)."""
     w = 1.0 / torch.arange(1, n_items + 1, device=device, dtype=torch.float64) ** alpha
@@ -250,6 +263,10 @@ def eval_block(dev, cuda, n, I, d, k, deg, tdeg, label):
             ev[name] = {"users_per_s": n / dt, "ms": dt * 1e3,
                         "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS[name], "unit": "TFLOP/s",
                                      "frac": tf / MFMA_PEAK_TFLOPS[name], "traffic": None}}
+            if name == "bf16" and SUSTAINED_BF16_TFLOPS:
+                # beside the nominal peak: what the instruction sustains on random operands at the clock the chip then holds
+                ev[name]["roofline"]["sustained_peak"] = SUSTAINED_BF16_TFLOPS
+                ev[name]["roofline"]["frac_of_sustained"] = tf / SUSTAINED_BF16_TFLOPS
         res[case] = ev
     return res
 
@@ -784,7 +801,7 @@ def main():
                     c5 = eval_block(dev, cuda, args.eval_users, 2_000_000, 128, 100, 10, 3, "C5 shape")
                     ev["c5"] = c5
                     ev["roofline"] = dict(c5["independent"]["bf16"]["roofline"],
-                                          kernel="score_topk_kernel (bf16 MFMA 32x32x16) + metrics, whole call",
+                                          kernel="score_topk_pp_kernel (bf16 MFMA 32x32x16) + metrics, whole call",
                                           workload="%d users x 2M items, d=128, k=100, independent factors" % args.eval_users)
                 out["eval"] = ev
             if not args.no_other:

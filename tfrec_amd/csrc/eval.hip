@@ -857,21 +857,23 @@ __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk
 // ------------------------------------------------------------------------------------------
 // bf16 scoring, d = 128, with 64 users per wave
 //
-// score_topk_kernel with sixteen waves of 32 users reads one kilobyte of A fragment from LDS per matrix instruction,
-// which for the four SIMDs of a CU is the 128 bytes per clock the LDS delivers: the LDS, not the matrix pipe, paces
-// that scan, and a wave's filter work sits between its matrix instructions.  Here a wave owns 64 users (two B-operand
-// sets, every A fragment feeds two matrix instructions), a workgroup is eight waves (two per SIMD, up to 256 registers
-// each), and the instruction stream of ONE wave keeps the matrix pipe fed by itself:
-//     phase A of a block of 32 items: the 8 matrix instructions of user set 0, and between them the group maxima of
-//                                     set 1's scores of the block before;
-//     phase B:                        the 8 matrix instructions of set 1, between them the group maxima of set 0's
-//                                     scores of this block and the LDS reads of the next block's A fragments (each
-//                                     fragment register is refilled right after its last use) and biases.
-// A SIMD issues about five vector instructions per matrix instruction without delaying the matrix pipe, so as long as no
-// score passes its user's threshold the matrix instructions of consecutive blocks follow each other without a gap.
-// Only a passing score leaves that stream (appends, compactions: the epilogue of score_topk_kernel), and then the
-// other wave of the SIMD has the pipe.  Results are those of score_topk_kernel<128, true, CAP> exactly: the same
-// products in the same order per score, the same filter, the same selection.
+// In score_topk_kernel a wave's filter work and its LDS reads sit between its matrix instructions, and four waves per
+// SIMD are meant to fill each other's gaps; the end of every tile lines them up again.  Here a wave owns 64 users (two
+// B-operand sets: every A fragment read from LDS feeds two matrix instructions), a workgroup is eight waves (two per
+// SIMD, up to 256 registers each), and the instruction stream of ONE wave keeps the matrix pipe fed by itself:
+//     phase A of a block of 32 items: the 8 matrix instructions of user set 0; between them the group maxima of set 1's
+//                                     scores of the block before, and one direct-to-LDS load of the next tile;
+//     phase B:                        the 8 matrix instructions of set 1; between them the group maxima of set 0's scores
+//                                     of this block and the LDS reads of the next block's A fragments (each fragment
+//                                     register is refilled right after its last use) and biases.
+// Measured on MI355X (tools/mfma_valu_overlap.hip): a SIMD issues about five vector instructions per matrix instruction
+// without delaying the matrix pipe, and its arbiter serves the older wave first.  So as long as no score passes its
+// user's threshold, the matrix instructions of consecutive blocks follow each other without a gap; only a passing score
+// leaves that stream (appends, compactions: the epilogue of score_topk_kernel), and then the other wave of the SIMD has
+// the pipe.  Item tiles go from global memory straight into LDS (global_load_lds_dwordx4: no staging registers, no
+// store pass at the end of a tile), one kilobyte per wave and block.
+// Results are those of score_topk_kernel<128, true, CAP> exactly: the same products in the same order per score, the
+// same filter rule, the same total order.
 // ------------------------------------------------------------------------------------------
 #ifndef TF_EVAL_PP
 #define TF_EVAL_PP 1
@@ -887,34 +889,26 @@ template <int D, int CAP>
 struct PpGeom {
     static constexpr int UW = 2, NW = 8, NT = 64 * NW, UB = 32 * NW * UW;   // user sets per wave, waves, threads, users per workgroup
     static constexpr int KS = D / 16;                        // matrix instructions per set and block
-    static constexpr int ROWB = D * 2 + 16, CPR = D * 2 / 16;
+    static constexpr int ROWB = D * 2;                       // LDS rows are not padded (see load_rows)
     static constexpr int TI = CAP <= 256 ? TF_EVAL_PP_TI : 192, NB = TI / 32;   // items and blocks per tile (as many as fit beside the sort buffers)
-    static constexpr int NLD = TI * CPR / NT;
     static_assert(KS == 8, "the interleaving below is written for eight matrix instructions per phase");
-    static_assert(NB >= 2 && NLD >= 1 && NLD * NT == TI * CPR && NT >= TI, "tile does not divide over the workgroup");
+    // a wave moves four rows per block of the scan: eight waves, one tile per NB blocks
+    static_assert(NB >= 2 && ROWB == 256 && 4 * NW * NB == TI && NT >= TI, "tile does not divide over the workgroup");
     static constexpr int QBYTES = TI * ROWB;
     static constexpr int LDS_BYTES = score_lds_bytes(TI, ROWB, NW, CAP);
     // the fragment refills of a tile's last block read one block past the tile (discarded): still inside the allocation
     static_assert(LDS_BYTES <= 160 * 1024 && 32 * ROWB <= 2 * TI * 4 + NW * CAP * 8, "tile buffers and sort buffers exceed the CU's LDS");
 };
 
-// a pointer to global memory that is the same in every lane, moved into scalar registers (the result keeps the global
-// address space, so that loads through it take the form scalar base + 32-bit lane offset)
+// a pointer into global memory that keeps its address space through pointer arithmetic
 template <class T>
 using global_ptr = __attribute__((address_space(1))) T *;
-template <class T>
-__device__ __forceinline__ global_ptr<const T> uniform_global(const T *p)
-{
-    const uint64_t u = reinterpret_cast<uint64_t>(p);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
-    return (global_ptr<const T>)(((uint64_t)hi << 32) | lo);
-}
 
 template <int D, int CAP>
 __global__ __launch_bounds__(512) void score_topk_pp_kernel(ScoreArgs a)
 {
     using G = PpGeom<D, CAP>;
-    constexpr int TI = G::TI, ROWB = G::ROWB, CPR = G::CPR, NLD = G::NLD, NB = G::NB, KS = G::KS, UW = G::UW, NT = G::NT;
+    constexpr int TI = G::TI, ROWB = G::ROWB, NB = G::NB, KS = G::KS, UW = G::UW;
     extern __shared__ __align__(16) char lds[];
     char *qbuf = lds;                                                   // [2][TI*ROWB]
     float *bias = reinterpret_cast<float *>(lds + 2 * G::QBYTES);        // [2][TI]
@@ -957,41 +951,34 @@ __global__ __launch_bounds__(512) void score_topk_pp_kernel(ScoreArgs a)
         }
     }
 
-    // staging of a tile through registers: thread t moves the 16-byte chunks t, t + NT, ... of the tile (chunk c = row
-    // c / CPR, column c % CPR).  Addresses are one uniform base per tile plus a per-thread 32-bit offset, so that no
-    // per-chunk address has to live in a register across the scan.
-    u32x4 stg[NLD];
+    // Staging of a tile straight into LDS: one global_load_lds_dwordx4 of a wave moves four rows of 256 bytes (lane l: row
+    // l / 16, 16-byte chunk l % 16 of the LDS image); wave w moves rows 4 * (8 * sb + w) ... + 3 of a tile with its sb-th
+    // instruction.  The LDS image has no row padding (the instruction writes its kilobyte contiguously), so it is
+    // XOR-swizzled against bank conflicts: chunk position c of row r holds the row's chunk c ^ (r & 15); the swizzle is on
+    // the source address.  Rows past the end of the item range read the last row (their bias of -inf keeps them out).
+    // The compiler does not see these loads (inline assembly): it neither counts them on the memory counter nor guards LDS
+    // reads against them; the waits are the explicit ones at the end of a tile.
+    const int rowlane = 4 * wave + (lane >> 4);
+    const global_ptr<const char> qsrc = (global_ptr<const char>)(reinterpret_cast<const char *>(a.Qt)) + (((lane & 15) ^ (rowlane & 15)) * 16);
+    const int last_item = (int)(it1 - 1);
+    const uint32_t lds_q = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)qbuf;
+    auto load_rows = [&](int item_base, int sb, int buf) {
+        int it = item_base + 32 * sb + rowlane;
+        it = it < last_item ? it : last_item;
+        const global_ptr<const char> src = qsrc + (uint64_t)(uint32_t)it * (D * 2);
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_q + (uint32_t)(buf * G::QBYTES + (8 * sb + wave) * 1024));
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
+    };
     float bstg = 0.f;
-    const uint32_t stg_off = (uint32_t)tid * 16u;
-    auto load_tile = [&](int64_t item_base) {
-        // both bases are made scalar registers here, per tile (else their per-thread sums are hoisted out of the scan
-        // and live in vector registers, or in scratch, for all of it)
-        const global_ptr<const char> tb = uniform_global(reinterpret_cast<const char *>(a.Qt) + (size_t)item_base * (D * 2));
-        const global_ptr<const float> bb = uniform_global(a.b + (a.item_lo + item_base));
-        // (rows past the end of the range carry a bias of -inf, which keeps them out of every list)
-        if (tid < TI) bstg = item_base + tid < it1 ? bb[tid] : -INFINITY;
-        if (item_base + TI <= it1) {
-#pragma unroll
-            for (int m = 0; m < NLD; ++m) stg[m] = *(global_ptr<const u32x4>)(tb + (stg_off + (uint32_t)(m * NT * 16)));
-        } else {
-            // the last tile of the range: rows past its end are zero
-#pragma unroll
-            for (int m = 0; m < NLD; ++m) {
-                const int64_t it = item_base + (tid + NT * m) / CPR;
-                stg[m] = it < it1 ? *(global_ptr<const u32x4>)(tb + (stg_off + (uint32_t)(m * NT * 16))) : u32x4{0, 0, 0, 0};
-            }
-        }
+    auto load_bias = [&](int64_t item_base) {
+        if (tid < TI) bstg = item_base + tid < it1 ? (a.b + (a.item_lo + item_base))[tid] : -INFINITY;
     };
-    const int stg_lds = (tid / CPR) * ROWB + (tid % CPR) * 16;
-    auto store_tile = [&](int buf) {
-        char *to = qbuf + buf * G::QBYTES + stg_lds;
+    // fragment of k-step ks, half h, of row uj of a block: chunk (2 * ks + h) ^ (uj & 15) of the row
+    int a_off[KS];
 #pragma unroll
-        for (int m = 0; m < NLD; ++m) *reinterpret_cast<u32x4 *>(to + m * (NT / CPR) * ROWB) = stg[m];
-        if (tid < TI) bias[buf * TI + tid] = bstg;
-    };
-
+    for (int ks = 0; ks < KS; ++ks) a_off[ks] = uj * ROWB + ((((uj & 15) ^ h) * 16) ^ (32 * ks));
     volatile uint64_t *mysort = sortbuf + wave * CAP;
-    const int lane_row_off = uj * ROWB + 16 * h, lane_bias_off = 4 * h;
+    const int lane_bias_off = 4 * h;
 
     bf16x8 af[KS];            // A fragments of the block whose matrix instructions come next
     f32x16 bv;                // its biases: the accumulators' starting value
@@ -1052,12 +1039,12 @@ __global__ __launch_bounds__(512) void score_topk_pp_kernel(ScoreArgs a)
     };
 
     const int64_t n_tiles = (it1 - it0 + TI - 1) / TI;
-    load_tile(it0);
-    store_tile(0);
-    // A tile's global loads are issued just before the barrier that ends the tile before the one they are stored in:
-    // the wave that reaches a barrier first (the one the SIMD's arbiter favours) has them back when the barrier opens,
-    // and the other one waits its turn for the matrix pipe anyway.
-    if (n_tiles > 1) load_tile(it0 + TI);
+#pragma unroll
+    for (int sb = 0; sb < NB; ++sb) load_rows((int)it0, sb, 0);
+    load_bias(it0);
+    if (tid < TI) bias[tid] = bstg;
+    if (n_tiles > 1) load_bias(it0 + TI);
+    __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0)
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[1][j] = -INFINITY;      // "the block before the first": nothing passes
@@ -1068,10 +1055,10 @@ __global__ __launch_bounds__(512) void score_topk_pp_kernel(ScoreArgs a)
         {
             // in the order the scan requests them (fragments 0 and 1, biases, the other fragments), so that the first
             // matrix instruction of a block waits for what it needs and no more, wherever the block was entered from
-            const char *arow = qbuf + buf * G::QBYTES + lane_row_off;
+            const char *arow = qbuf + buf * G::QBYTES;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                af[ks] = *reinterpret_cast<const bf16x8 *>(arow + 32 * ks);
+                af[ks] = *reinterpret_cast<const bf16x8 *>(arow + a_off[ks]);
                 if (ks == 1) read_bias(bv, bias + buf * TI + lane_bias_off);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1080,7 +1067,8 @@ __global__ __launch_bounds__(512) void score_topk_pp_kernel(ScoreArgs a)
 #pragma unroll 1
         for (int sb = 0; sb < NB; ++sb) {
             const int64_t nb = tile * NB + sb;
-            const char *arow_next = qbuf + buf * G::QBYTES + (sb + 1) * (32 * ROWB) + lane_row_off;   // past the tile for its last block
+            const char *arow_next = qbuf + buf * G::QBYTES + (sb + 1) * (32 * ROWB);   // past the tile for its last block
+            const int next_base = (int)(it0 + (tile + 1) * TI);
             const float *bias_next = bias + buf * TI + (sb + 1) * 32 + lane_bias_off;
             // ---- phase A: set 0 of block nb; maxima of set 1 of block nb - 1
             __builtin_amdgcn_sched_barrier(0);
@@ -1089,6 +1077,7 @@ __global__ __launch_bounds__(512) void score_topk_pp_kernel(ScoreArgs a)
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], pb[0][ks], ks == 0 ? bv : acc[0], 0, 0, 0);
                 if (ks >= 1 && ks <= 4) gm1[ks - 1] = group_max(acc[1], ks - 1);
                 if (ks == 5) mx1 = fmaxf(fmaxf(gm1[0], gm1[1]), fmaxf(gm1[2], gm1[3]));
+                if (ks == 6) load_rows(next_base, sb, buf ^ 1);      // this wave's sb-th kilobyte of the next tile
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (__ballot(mx1 > th[1]) != 0) insert.template operator()<1>(nb - 1, gm1);
@@ -1100,7 +1089,7 @@ __global__ __launch_bounds__(512) void score_topk_pp_kernel(ScoreArgs a)
                 // the biases keep registers of their own up to here (else the accumulator is built in theirs and copied out
                 // when they are read again); then the next block's are requested
                 if (ks == 0) asm volatile("" ::"v"(bv));
-                af[ks] = *reinterpret_cast<const bf16x8 *>(arow_next + 32 * ks);
+                af[ks] = *reinterpret_cast<const bf16x8 *>(arow_next + a_off[ks]);
                 if (ks == 1) read_bias(bv, bias_next);
                 if (ks >= 2 && ks <= 5) gm0[ks - 2] = group_max(acc[0], ks - 2);
                 if (ks == 6) mx0 = fmaxf(fmaxf(gm0[0], gm0[1]), fmaxf(gm0[2], gm0[3]));
@@ -1111,8 +1100,10 @@ __global__ __launch_bounds__(512) void score_topk_pp_kernel(ScoreArgs a)
         TF_PROF_ADD(1, prof_t_blk);
         // the next tile: this thread's part into the other buffer, visible to all after the barrier
         [[maybe_unused]] const unsigned long long prof_t_bar = TF_PROF_T();
-        if (tile + 1 < n_tiles) store_tile(buf ^ 1);
-        if (tile + 2 < n_tiles) load_tile(it0 + (tile + 2) * TI);
+        // this wave's rows of the next tile have landed, and its biases (requested a tile ago) are here
+        __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0)
+        if (tile + 1 < n_tiles && tid < TI) bias[(buf ^ 1) * TI + tid] = bstg;
+        if (tile + 2 < n_tiles) load_bias(it0 + (tile + 2) * TI);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         TF_PROF_ADD(2, prof_t_bar);
