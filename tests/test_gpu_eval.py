@@ -411,3 +411,50 @@ def test_sums_only_metrics_agree_with_the_per_user_curves(dev, golden_eval, case
         np.testing.assert_allclose(via_rows, rows.numpy().astype(np.float64).sum(0), rtol=1e-12)
         for sums in (direct, via_rows):
             np.testing.assert_allclose((sums / n).reshape(5, k), g["metrics_k%d" % k], rtol=5e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("shape", ["partly_filled", "few_users_many_splits", "k150_long_lists", "shard_rows", "one_short_tile"])
+def test_both_bf16_kernels_give_identical_lists(dev, shape):
+    """bf16 scoring at a padded factor size of 128 runs score_topk_pp_kernel (64 users per wave, tiles straight into a
+    swizzled LDS image); TFREC_AMD_SCORE_KERNEL=1 keeps score_topk_kernel for that shape.  Both form every score from the
+    same products in the same order and rank under the same total order, so ids AND scores must be bit-identical --
+    whatever the two kernels' thresholds did on the way (the second one's compactions cut by histogram)."""
+    import os
+    from tfrec_amd.device import SCORE_BF16
+    U, I, d, n, k, compact = {"partly_filled": (3000, 9001, 128, 1337, 100, False),
+                              "few_users_many_splits": (400, 70000, 100, 70, 100, False),
+                              "k150_long_lists": (1500, 6000, 128, 1100, 150, False),
+                              "shard_rows": (2000, 5003, 96, 900, 50, True),
+                              "one_short_tile": (700, 131, 128, 600, 20, False)}[shape]
+    rng = np.random.default_rng(len(shape) * 7 + k)
+    P = rng.uniform(-0.5, 0.5, (U, d)).astype(np.float32)
+    Q = rng.uniform(-0.5, 0.5, (I, d)).astype(np.float32)
+    b = rng.normal(0, 0.3, I).astype(np.float32)
+    users = np.sort(rng.choice(U, n, replace=False)).astype(np.int32)
+    lens = rng.choice([0, 2, 30, 200, 600], U) if I > 1000 else rng.choice([0, 2, 30], U)
+    indptr = np.zeros(U + 1, np.int64); indptr[1:] = np.cumsum(lens)
+    indices = np.concatenate([np.sort(rng.choice(I, m, replace=False)) for m in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
+    train = dcsr(dev, indptr, indices)
+    dQ, db, du = dev.array(Q), dev.array(b), dev.array(users)
+
+    def run():
+        if compact:     # the item-sharded evaluator's call: row r of P belongs to users[r], ids are offset
+            return dev.score_topk_shard(dev.array(P[users]), dQ, db, 1000, du, k, train, SCORE_BF16)
+        return dev.score_topk(dev.array(P), dQ, db, du, k, train=train, mode=SCORE_BF16)
+
+    old = os.environ.get("TFREC_AMD_SCORE_KERNEL")
+    try:
+        os.environ["TFREC_AMD_SCORE_KERNEL"] = "1"
+        ids1, sc1 = run()
+        ids1, sc1 = ids1.numpy().copy(), sc1.numpy().copy()
+        os.environ["TFREC_AMD_SCORE_KERNEL"] = "0"
+        ids2, sc2 = run()
+        ids2, sc2 = ids2.numpy().copy(), sc2.numpy().copy()
+    finally:
+        if old is None:
+            os.environ.pop("TFREC_AMD_SCORE_KERNEL", None)
+        else:
+            os.environ["TFREC_AMD_SCORE_KERNEL"] = old
+    assert np.array_equal(ids1, ids2)
+    assert np.array_equal(sc1.view(np.uint32), sc2.view(np.uint32))
+    assert (ids1 >= 0).sum() > 0.9 * ids1.size or I < k + 700      # real lists, not empty ones

@@ -1406,31 +1406,42 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const double *__restr
 #endif
 static int cap_for_k(int k) { return k <= TF_EVAL_CAP256_MAXK ? 256 : (k <= 240 ? 512 : 0); }
 
+// the dynamic-LDS limit is a per-device attribute of a kernel: set once on every device an instantiation runs on
+// (bit = device ordinal; devices beyond 63 set it on every launch)
+static int raise_lds_limit(tfrec_ctx *ctx, const void *kernel, int bytes, std::atomic<uint64_t> &done)
+{
+    const uint64_t dev_bit = ctx->device < 64 ? (1ull << ctx->device) : 0ull;
+    if (!(done.load(std::memory_order_acquire) & dev_bit)) {
+        TF_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        done.fetch_or(dev_bit, std::memory_order_release);
+    }
+    return TFREC_OK;
+}
+
+template <int D, int CAP>
+static int launch_score_pp(tfrec_ctx *ctx, const ScoreArgs &a, int splits)
+{
+    using G = PpGeom<D, CAP>;
+    static std::atomic<uint64_t> attr_devices{0};
+    TF_TRY(raise_lds_limit(ctx, reinterpret_cast<const void *>(&score_topk_pp_kernel<D, CAP>), G::LDS_BYTES, attr_devices));
+    const int user_blocks = (int)((a.n + G::UB - 1) / G::UB);
+    score_topk_pp_kernel<D, CAP><<<dim3(user_blocks, splits), G::NT, G::LDS_BYTES, ctx->stream>>>(a);
+    TF_HIP(hipGetLastError());
+    return TFREC_OK;
+}
+
 template <int D, bool BF16, int CAP>
 static int launch_score(tfrec_ctx *ctx, const ScoreArgs &a, int user_blocks, int splits)
 {
-    // the dynamic-LDS limit is a per-device attribute of the kernel: set once on every device this
-    // instantiation runs on (bit = device ordinal; devices beyond 63 set it on every launch)
-    static std::atomic<uint64_t> attr_devices{0};
-    const uint64_t dev_bit = ctx->device < 64 ? (1ull << ctx->device) : 0ull;
     if constexpr (TF_EVAL_PP && BF16 && D == 128) {
-        using PG = PpGeom<D, CAP>;
-        if (!(attr_devices.load(std::memory_order_acquire) & dev_bit)) {
-            TF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&score_topk_pp_kernel<D, CAP>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, PG::LDS_BYTES));
-            attr_devices.fetch_or(dev_bit, std::memory_order_release);
-        }
-        user_blocks = (int)((a.n + PG::UB - 1) / PG::UB);
-        score_topk_pp_kernel<D, CAP><<<dim3(user_blocks, splits), PG::NT, PG::LDS_BYTES, ctx->stream>>>(a);
-        TF_HIP(hipGetLastError());
-        return TFREC_OK;
+        // developer switch, read at every launch: TFREC_AMD_SCORE_KERNEL=1 keeps score_topk_kernel for this shape too
+        // (the two kernels give identical lists; tests/test_gpu_eval.py compares them)
+        const char *force = std::getenv("TFREC_AMD_SCORE_KERNEL");
+        if (!(force && force[0] == '1')) return launch_score_pp<D, CAP>(ctx, a, splits);
     }
     using G = ScoreGeom<D, BF16, CAP>;
-    if (!(attr_devices.load(std::memory_order_acquire) & dev_bit)) {
-        TF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&score_topk_kernel<D, BF16, CAP>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
-        attr_devices.fetch_or(dev_bit, std::memory_order_release);
-    }
+    static std::atomic<uint64_t> attr_devices{0};
+    TF_TRY(raise_lds_limit(ctx, reinterpret_cast<const void *>(&score_topk_kernel<D, BF16, CAP>), G::LDS_BYTES, attr_devices));
     // the caller counts workgroups of 128 users; this instantiation may hold more
     constexpr int UB = 32 * G::NW * ScoreWave<D, BF16, CAP>::UW;
     user_blocks = (int)((a.n + UB - 1) / UB);
