@@ -855,7 +855,7 @@ __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk
 }
 
 // ------------------------------------------------------------------------------------------
-// bf16 scoring, d = 128, with 64 users per wave
+// bf16 scoring with 64 users per wave (d = 128; d = 64 on request)
 //
 // In score_topk_kernel a wave's filter work and its LDS reads sit between its matrix instructions, and four waves per
 // SIMD are meant to fill each other's gaps; the end of every tile lines them up again.  Here a wave owns 64 users (two
@@ -875,6 +875,8 @@ __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk
 // Results are those of score_topk_kernel<128, true, CAP> exactly: the same products in the same order per score, the
 // same filter rule, the same total order.
 // ------------------------------------------------------------------------------------------
+// 0: never; 1: for d = 128; 2: for d = 64 too (measured slower there than score_topk_kernel: a block is then four matrix
+// instructions per user set, half the shadow for the same filter work)
 #ifndef TF_EVAL_PP
 #define TF_EVAL_PP 1
 #endif
@@ -890,10 +892,12 @@ struct PpGeom {
     static constexpr int UW = 2, NW = 8, NT = 64 * NW, UB = 32 * NW * UW;   // user sets per wave, waves, threads, users per workgroup
     static constexpr int KS = D / 16;                        // matrix instructions per set and block
     static constexpr int ROWB = D * 2;                       // LDS rows are not padded (see load_rows)
-    static constexpr int TI = CAP <= 256 ? TF_EVAL_PP_TI : 192, NB = TI / 32;   // items and blocks per tile (as many as fit beside the sort buffers)
-    static_assert(KS == 8, "the interleaving below is written for eight matrix instructions per phase");
-    // a wave moves four rows per block of the scan: eight waves, one tile per NB blocks
-    static_assert(NB >= 2 && ROWB == 256 && 4 * NW * NB == TI && NT >= TI, "tile does not divide over the workgroup");
+    static constexpr int CPR = ROWB / 16, RPI = 1024 / ROWB; // 16-byte chunks per row; rows per direct-to-LDS instruction of a wave
+    // items per tile: as many as fit twice beside the sort buffers, a divisor of the item-split granularity (768)
+    static constexpr int TI = D == 128 ? (CAP <= 256 ? TF_EVAL_PP_TI : 192) : 384, NB = TI / 32;   // and blocks per tile
+    static constexpr int IPW = TI / (RPI * NW), BPI = NB / IPW;             // load instructions per wave and tile; blocks per instruction
+    static_assert(KS == 8 || KS == 4, "the interleaving below is written for eight or four matrix instructions per phase");
+    static_assert(NB >= 2 && IPW * RPI * NW == TI && BPI * IPW == NB && NT >= TI && 768 % TI == 0, "tile does not divide over the workgroup");
     static constexpr int QBYTES = TI * ROWB;
     static constexpr int LDS_BYTES = score_lds_bytes(TI, ROWB, NW, CAP);
     // the fragment refills of a tile's last block read one block past the tile (discarded): still inside the allocation
@@ -908,7 +912,7 @@ template <int D, int CAP>
 __global__ __launch_bounds__(512) void score_topk_pp_kernel(ScoreArgs a)
 {
     using G = PpGeom<D, CAP>;
-    constexpr int TI = G::TI, ROWB = G::ROWB, NB = G::NB, KS = G::KS, UW = G::UW;
+    constexpr int TI = G::TI, ROWB = G::ROWB, NB = G::NB, KS = G::KS, UW = G::UW, CPR = G::CPR, RPI = G::RPI, IPW = G::IPW, BPI = G::BPI;
     extern __shared__ __align__(16) char lds[];
     char *qbuf = lds;                                                   // [2][TI*ROWB]
     float *bias = reinterpret_cast<float *>(lds + 2 * G::QBYTES);        // [2][TI]
@@ -951,32 +955,34 @@ __global__ __launch_bounds__(512) void score_topk_pp_kernel(ScoreArgs a)
         }
     }
 
-    // Staging of a tile straight into LDS: one global_load_lds_dwordx4 of a wave moves four rows of 256 bytes (lane l: row
-    // l / 16, 16-byte chunk l % 16 of the LDS image); wave w moves rows 4 * (8 * sb + w) ... + 3 of a tile with its sb-th
-    // instruction.  The LDS image has no row padding (the instruction writes its kilobyte contiguously), so it is
-    // XOR-swizzled against bank conflicts: chunk position c of row r holds the row's chunk c ^ (r & 15); the swizzle is on
-    // the source address.  Rows past the end of the item range read the last row (their bias of -inf keeps them out).
-    // The compiler does not see these loads (inline assembly): it neither counts them on the memory counter nor guards LDS
-    // reads against them; the waits are the explicit ones at the end of a tile.
-    const int rowlane = 4 * wave + (lane >> 4);
-    const global_ptr<const char> qsrc = (global_ptr<const char>)(reinterpret_cast<const char *>(a.Qt)) + (((lane & 15) ^ (rowlane & 15)) * 16);
+    // Staging of a tile straight into LDS: one global_load_lds_dwordx4 of a wave moves a kilobyte, RPI rows of the tile
+    // (lane l: row l / CPR, 16-byte chunk l % CPR of the LDS image); wave w moves rows RPI * (8 * m + w) ... of a tile
+    // with its m-th instruction.  The LDS image has no row padding (the instruction writes its kilobyte contiguously), so
+    // it is XOR-swizzled against bank conflicts: chunk position c of row r holds the row's chunk c ^ swz(r), swz(r) =
+    // r & 15 for rows of 256 bytes and (r >> 1) & 7 for rows of 128 (sixteen consecutive rows then spread every fragment
+    // read over all banks); the swizzle is on the source address.  Rows past the end of the item range read the last row
+    // (their bias of -inf keeps them out).  The compiler does not see these loads (inline assembly): it neither counts
+    // them on the memory counter nor guards LDS reads against them; the waits are the explicit ones at the end of a tile.
+    auto swz = [](int row) { return D == 128 ? (row & 15) : ((row >> 1) & 7); };
+    const int rowlane = RPI * wave + lane / CPR;            // this lane's row among the RPI * 8 rows one instruction round moves
+    const global_ptr<const char> qsrc = (global_ptr<const char>)(reinterpret_cast<const char *>(a.Qt)) + (((lane % CPR) ^ swz(rowlane)) * 16);
     const int last_item = (int)(it1 - 1);
     const uint32_t lds_q = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)qbuf;
-    auto load_rows = [&](int item_base, int sb, int buf) {
-        int it = item_base + 32 * sb + rowlane;
+    auto load_rows = [&](int item_base, int m, int buf) {
+        int it = item_base + RPI * 8 * m + rowlane;
         it = it < last_item ? it : last_item;
-        const global_ptr<const char> src = qsrc + (uint64_t)(uint32_t)it * (D * 2);
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_q + (uint32_t)(buf * G::QBYTES + (8 * sb + wave) * 1024));
+        const global_ptr<const char> src = qsrc + (uint64_t)(uint32_t)it * ROWB;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_q + (uint32_t)(buf * G::QBYTES + (8 * m + wave) * 1024));
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
     };
     float bstg = 0.f;
     auto load_bias = [&](int64_t item_base) {
         if (tid < TI) bstg = item_base + tid < it1 ? (a.b + (a.item_lo + item_base))[tid] : -INFINITY;
     };
-    // fragment of k-step ks, half h, of row uj of a block: chunk (2 * ks + h) ^ (uj & 15) of the row
+    // fragment of k-step ks, half h, of row uj of a block: chunk (2 * ks + h) ^ swz(uj) of the row
     int a_off[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) a_off[ks] = uj * ROWB + ((((uj & 15) ^ h) * 16) ^ (32 * ks));
+    for (int ks = 0; ks < KS; ++ks) a_off[ks] = uj * ROWB + (((swz(uj) ^ h) * 16) ^ (32 * ks));
     volatile uint64_t *mysort = sortbuf + wave * CAP;
     const int lane_bias_off = 4 * h;
 
@@ -1040,7 +1046,7 @@ __global__ __launch_bounds__(512) void score_topk_pp_kernel(ScoreArgs a)
 
     const int64_t n_tiles = (it1 - it0 + TI - 1) / TI;
 #pragma unroll
-    for (int sb = 0; sb < NB; ++sb) load_rows((int)it0, sb, 0);
+    for (int m = 0; m < IPW; ++m) load_rows((int)it0, m, 0);
     load_bias(it0);
     if (tid < TI) bias[tid] = bstg;
     if (n_tiles > 1) load_bias(it0 + TI);
@@ -1075,9 +1081,15 @@ __global__ __launch_bounds__(512) void score_topk_pp_kernel(ScoreArgs a)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], pb[0][ks], ks == 0 ? bv : acc[0], 0, 0, 0);
-                if (ks >= 1 && ks <= 4) gm1[ks - 1] = group_max(acc[1], ks - 1);
-                if (ks == 5) mx1 = fmaxf(fmaxf(gm1[0], gm1[1]), fmaxf(gm1[2], gm1[3]));
-                if (ks == 6) load_rows(next_base, sb, buf ^ 1);      // this wave's sb-th kilobyte of the next tile
+                // (with four matrix instructions per phase the vector work comes two items to a slot)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (ks == 1 + g * KS / 8) gm1[g] = group_max(acc[1], g);
+                if (ks == 1 + KS / 2) mx1 = fmaxf(fmaxf(gm1[0], gm1[1]), fmaxf(gm1[2], gm1[3]));
+                if (ks == (KS == 8 ? 6 : 3)) {
+                    // this wave's next kilobyte of the next tile
+                    if (BPI == 1 || sb % BPI == 0) load_rows(next_base, sb / BPI, buf ^ 1);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (__ballot(mx1 > th[1]) != 0) insert.template operator()<1>(nb - 1, gm1);
@@ -1091,8 +1103,10 @@ __global__ __launch_bounds__(512) void score_topk_pp_kernel(ScoreArgs a)
                 if (ks == 0) asm volatile("" ::"v"(bv));
                 af[ks] = *reinterpret_cast<const bf16x8 *>(arow_next + a_off[ks]);
                 if (ks == 1) read_bias(bv, bias_next);
-                if (ks >= 2 && ks <= 5) gm0[ks - 2] = group_max(acc[0], ks - 2);
-                if (ks == 6) mx0 = fmaxf(fmaxf(gm0[0], gm0[1]), fmaxf(gm0[2], gm0[3]));
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (ks == (KS == 8 ? 2 + g : 1 + g / 2)) gm0[g] = group_max(acc[0], g);
+                if (ks == (KS == 8 ? 6 : 3)) mx0 = fmaxf(fmaxf(gm0[0], gm0[1]), fmaxf(gm0[2], gm0[3]));
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (__ballot(mx0 > th[0]) != 0) insert.template operator()<0>(nb, gm0);
@@ -1433,7 +1447,7 @@ static int launch_score_pp(tfrec_ctx *ctx, const ScoreArgs &a, int splits)
 template <int D, bool BF16, int CAP>
 static int launch_score(tfrec_ctx *ctx, const ScoreArgs &a, int user_blocks, int splits)
 {
-    if constexpr (TF_EVAL_PP && BF16 && D == 128) {
+    if constexpr (TF_EVAL_PP && BF16 && (D == 128 || (D == 64 && TF_EVAL_PP >= 2))) {
         // developer switch, read at every launch: TFREC_AMD_SCORE_KERNEL=1 keeps score_topk_kernel for this shape too
         // (the two kernels give identical lists; tests/test_gpu_eval.py compares them)
         const char *force = std::getenv("TFREC_AMD_SCORE_KERNEL");

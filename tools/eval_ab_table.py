@@ -50,6 +50,7 @@ WHAT = {
     "glds": "apx + tiles straight into LDS (`global_load_lds_dwordx4`, swizzled image): the shipped kernel",
     "gldsab1": "glds, no score passes the filter",
     "insprio": "glds + `s_setprio 3` in the pass path",
+    "pp64": "glds, and the second kernel for d=64 as well (four matrix instructions per phase, tiles of 384 items) -- `-DTF_EVAL_PP=2`",
 }
 
 
