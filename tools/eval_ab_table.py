@@ -50,6 +50,9 @@ WHAT = {
     "glds": "apx + tiles straight into LDS (`global_load_lds_dwordx4`, swizzled image): the shipped kernel",
     "gldsab1": "glds, no score passes the filter",
     "insprio": "glds + `s_setprio 3` in the pass path",
+    "cw4": "glds with a counted wait (`vmcnt(4)`) instead of `vmcnt(0)` at the end of a compaction",
+    "nw4": "glds as two workgroups of four waves x 64 users per CU (one wave per SIMD each, own tiles of 128 items): a held-up workgroup leaves the CU to the other one, but every tile is only four blocks long (not kept in the source)",
+    "nw4ab1": "nw4, no score passes the filter",
     "pp64": "glds, and the second kernel for d=64 as well (four matrix instructions per phase, tiles of 384 items) -- `-DTF_EVAL_PP=2`",
 }
 
