@@ -197,6 +197,11 @@ __device__ __forceinline__ int wave_compact(uint64_t *__restrict__ list, int cnt
 
 // Developer build only: per-wave cycle counts of the scan's parts, summed into tf_prof.
 #ifdef TF_EVAL_PROFILE
+__device__ unsigned long long tf_trace[8 * 64 * 4];     // [wave][tile][tile start, blocks done, barrier entered, barrier left] of one workgroup
+extern "C" int tfrec_debug_trace(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(tf_trace), sizeof(unsigned long long) * 8 * 64 * 4) == hipSuccess ? 0 : -1;
+}
 __device__ unsigned long long tf_prof[16];
 #define TF_PROF_T() __builtin_readcyclecounter()
 #define TF_PROF_ADD(i, t0) prof_acc[i] += __builtin_readcyclecounter() - (t0)
@@ -883,7 +888,8 @@ __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk
 #ifndef TF_EVAL_PP_TI
 #define TF_EVAL_PP_TI 256
 #endif
-// developer ablation (never defined in the shipped build): 1 = no score passes the filter
+// developer ablations (never defined in the shipped build): 1 = no score passes the filter, 2 = also no fragment reads
+// inside a tile, 3 = also no bias reads inside a tile
 #ifndef TF_EVAL_PP_ABLATE
 #define TF_EVAL_PP_ABLATE 0
 #endif
@@ -1055,6 +1061,7 @@ __global__ __launch_bounds__(512) void score_topk_pp_kernel(ScoreArgs a)
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[1][j] = -INFINITY;      // "the block before the first": nothing passes
     float gm0[4], gm1[4], mx0 = -INFINITY, mx1 = -INFINITY;
+    uint64_t pass0 = 0, pass1 = 0;
 #pragma unroll 1
     for (int64_t tile = 0; tile < n_tiles; ++tile) {
         const int buf = (int)(tile & 1);
@@ -1070,6 +1077,10 @@ __global__ __launch_bounds__(512) void score_topk_pp_kernel(ScoreArgs a)
             }
         }
         [[maybe_unused]] const unsigned long long prof_t_blk = TF_PROF_T();
+#ifdef TF_EVAL_PROFILE
+        const bool tracing = blockIdx.x == 7 && blockIdx.y == 0 && tile >= 1000 && tile < 1064 && lane == 0;
+        if (tracing) tf_trace[(wave * 64 + (tile - 1000)) * 4 + 0] = prof_t_blk;
+#endif
 #pragma unroll 1
         for (int sb = 0; sb < NB; ++sb) {
             const int64_t nb = tile * NB + sb;
@@ -1086,13 +1097,14 @@ __global__ __launch_bounds__(512) void score_topk_pp_kernel(ScoreArgs a)
                 for (int g = 0; g < 4; ++g)
                     if (ks == 1 + g * KS / 8) gm1[g] = group_max(acc[1], g);
                 if (ks == 1 + KS / 2) mx1 = fmaxf(fmaxf(gm1[0], gm1[1]), fmaxf(gm1[2], gm1[3]));
+                if (ks == 2 + KS / 2) pass1 = __ballot(mx1 > th[1]);      // decided before the phase's last instructions: no wait at the branch
                 if (ks == (KS == 8 ? 6 : 3)) {
                     // this wave's next kilobyte of the next tile
                     if (BPI == 1 || sb % BPI == 0) load_rows(next_base, sb / BPI, buf ^ 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (__ballot(mx1 > th[1]) != 0) insert.template operator()<1>(nb - 1, gm1);
+            if (pass1 != 0) [[unlikely]] insert.template operator()<1>(nb - 1, gm1);
             // ---- phase B: set 1 of block nb; maxima of set 0 of block nb; operands of block nb + 1
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1101,17 +1113,22 @@ __global__ __launch_bounds__(512) void score_topk_pp_kernel(ScoreArgs a)
                 // the biases keep registers of their own up to here (else the accumulator is built in theirs and copied out
                 // when they are read again); then the next block's are requested
                 if (ks == 0) asm volatile("" ::"v"(bv));
-                af[ks] = *reinterpret_cast<const bf16x8 *>(arow_next + a_off[ks]);
-                if (ks == 1) read_bias(bv, bias_next);
+                if (TF_EVAL_PP_ABLATE < 2) af[ks] = *reinterpret_cast<const bf16x8 *>(arow_next + a_off[ks]);
+                if (ks == 1 && TF_EVAL_PP_ABLATE < 3) read_bias(bv, bias_next);
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     if (ks == (KS == 8 ? 2 + g : 1 + g / 2)) gm0[g] = group_max(acc[0], g);
                 if (ks == (KS == 8 ? 6 : 3)) mx0 = fmaxf(fmaxf(gm0[0], gm0[1]), fmaxf(gm0[2], gm0[3]));
+                if (KS == 8 && ks == 7) pass0 = __ballot(mx0 > th[0]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (__ballot(mx0 > th[0]) != 0) insert.template operator()<0>(nb, gm0);
+            if (KS != 8) pass0 = __ballot(mx0 > th[0]);
+            if (pass0 != 0) [[unlikely]] insert.template operator()<0>(nb, gm0);
         }
         TF_PROF_ADD(1, prof_t_blk);
+#ifdef TF_EVAL_PROFILE
+        if (tracing) tf_trace[(wave * 64 + (tile - 1000)) * 4 + 1] = TF_PROF_T();
+#endif
         // the next tile: this thread's part into the other buffer, visible to all after the barrier
         [[maybe_unused]] const unsigned long long prof_t_bar = TF_PROF_T();
         // this wave's rows of the next tile have landed, and its biases (requested a tile ago) are here
@@ -1121,10 +1138,16 @@ __global__ __launch_bounds__(512) void score_topk_pp_kernel(ScoreArgs a)
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         TF_PROF_ADD(2, prof_t_bar);
+#ifdef TF_EVAL_PROFILE
+        if (tracing) tf_trace[(wave * 64 + (tile - 1000)) * 4 + 2] = TF_PROF_T();
+#endif
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         TF_PROF_ADD(3, prof_t_bar);
+#ifdef TF_EVAL_PROFILE
+        if (tracing) tf_trace[(wave * 64 + (tile - 1000)) * 4 + 3] = TF_PROF_T();
+#endif
     }
     // set 1 of the last block
 #pragma unroll
