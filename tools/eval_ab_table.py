@@ -9,7 +9,7 @@ import re
 import sys
 
 WHAT = {
-    "evbase": "round-2 kernel (`score_topk_kernel`, sixteen waves x 32 users): two tiles of 192 items, one workgroup barrier per tile",
+    "evbase": "first kernel as it stood before these experiments (`score_topk_kernel`, sixteen waves x 32 users): two tiles of 192 items, one workgroup barrier per tile",
     "pp0": "`score_topk_kernel` for d=128 too (`-DTF_EVAL_PP=0`), exact descent in compactions",
     "pp0apx": "`score_topk_kernel` for d=128 too, histogram cut in compactions",
     "ring": "ring of 6 tiles of 64 items guarded by per-slot counters in LDS, a tile staged 3 ahead (no workgroup barrier; a wave may fall 3 tiles behind) -- `-DTF_EVAL_RING=1`",
@@ -100,7 +100,7 @@ def main():
             out += ["## %s (`%s`)" % (title, base), ""] + ["    " + ln for ln in lines] + [""]
     out += ["## Reading", "",
             "First kernel (`score_topk_kernel`): none of its variants is kept.  Letting waves drift apart (ring), earlier fragment reads, priorities,",
-            "compactions moved into the barrier wait, staggered or rotated waves: all within -2 % ... +38 % of the round-2 kernel.  Its per-wave profile",
+            "compactions moved into the barrier wait, staggered or rotated waves: all within -2 % ... +38 % of that kernel as it stood.  Its per-wave profile",
             "(28 % of a wave's cycles between the end of a tile and the start of the next, in every variant) is four waves per SIMD whose filter work and",
             "LDS reads sit between their matrix instructions and who line up again at every tile end.", "",
             "Second kernel (`score_topk_pp_kernel`): the barrier-per-segment form loses (every pass event of any of four waves stretches the segment of",
