@@ -50,6 +50,12 @@ WHAT = {
     "glds": "apx + tiles straight into LDS (`global_load_lds_dwordx4`, swizzled image): the shipped kernel",
     "gldsab1": "glds, no score passes the filter",
     "insprio": "glds + `s_setprio 3` in the pass path",
+    "br": "glds + a phase's branch decided before its last matrix instructions, pass path out of line: the shipped kernel",
+    "base": "the shipped kernel",
+    "sl1": "shipped kernel, the older wave of every SIMD sleeps 64 cycles per block (to let the younger one keep up)",
+    "sl2": "the same, 128 cycles",
+    "sl3": "the same, 192 cycles",
+    "yp1": "shipped kernel, `s_setprio 1` in the younger wave of every SIMD",
     "cw4": "glds with a counted wait (`vmcnt(4)`) instead of `vmcnt(0)` at the end of a compaction",
     "nw4": "glds as two workgroups of four waves x 64 users per CU (one wave per SIMD each, own tiles of 128 items): a held-up workgroup leaves the CU to the other one, but every tile is only four blocks long (not kept in the source)",
     "nw4ab1": "nw4, no score passes the filter",
