@@ -97,6 +97,7 @@ def main():
             out += ["Cycle counts per wave of `%s` (`-DTF_EVAL_PROFILE`: shader-clock reads around the parts of the scan; the reads"
                     " themselves slow the kernel by about a tenth), C5 %s:" % (n, mo), "", "    " + p, ""]
     for base, title in ((tag + "_evalprof.log", "First kernel, `-DTF_EVAL_PROFILE` build, C5 random, two calls"),
+                        (tag + "_c2_prof.log", "First kernel, `-DTF_EVAL_PROFILE` build, C2 shape (200k items, d=64, k=50), random then biased (per wave of 32 users)"),
                         (tag + "_pp_prof5.log", "Second kernel as shipped, `-DTF_EVAL_PROFILE` build, C5 random then biased (per wave of 64 users; `filter+insert` = all of a tile's blocks, "
                                                 "`compaction` = end of tile before the barrier, `store+barrier` = end of tile with the barrier, `passing tiles` = pass events, "
                                                 "`id phases / tile store` = cycles in pass events without compactions, `tile load wait` = cycles in compactions)")):
