@@ -60,6 +60,12 @@ WHAT = {
     "nw4": "glds as two workgroups of four waves x 64 users per CU (one wave per SIMD each, own tiles of 128 items): a held-up workgroup leaves the CU to the other one, but every tile is only four blocks long (not kept in the source)",
     "nw4ab1": "nw4, no score passes the filter",
     "twolevel": "shipped kernel + a second threshold level left by every compaction (a histogram bucket edge near rank 3k/4 with its count; appends at or above it are counted and it becomes the threshold once k entries reach it) -- `tools/experiments/eval_two_level.patch`",
+    "head": "shipped kernel with a tile's first block staged two tiles ahead into buffers of its own, so that the last block of a tile refills its operand registers from the next tile's first block and no tile starts with fragment reads; two tile loads per block (all landed long before the tile's end) -- `tools/experiments/eval_head_buffers.patch`",
+    "head2": "the same",
+    "head1": "the same with one tile load per block",
+    "baseab1": "shipped kernel, no score passes the filter",
+    "head2ab1": "head2, no score passes the filter",
+    "head1ab1": "head1, no score passes the filter",
     "pp64": "glds, and the second kernel for d=64 as well (four matrix instructions per phase, tiles of 384 items) -- `-DTF_EVAL_PP=2`",
 }
 
@@ -116,6 +122,9 @@ def main():
             "scratch reloads around the tile loads were gone (explicit waits at the end of a compaction and of a tile, scalar bases), then level; the",
             "histogram cut gives 2-4 %, tiles straight into LDS another 3-5 %.  With no score passing the filter the same kernel runs at 92-95 ms:",
             "the pass path and the compactions are a fifth of the time with independent factors, a tenth with biased ones.",
+            "Taking the first fragment reads of a tile and the wait for the last tile load off the path after the barrier (head buffers) is 1-2 % SLOWER",
+            "even with no score passing: those cycles are not what holds the tile period above the pipe's time -- the two waves of a SIMD",
+            "running unevenly are (`profiles/r3_eval_trace.md`).",
             "A second threshold level between compactions (fewer appends per scanned item in theory: a tenth to a sixth) changes nothing measurable:",
             "the cycles a wave spends appending are mostly cycles in which the other wave of its SIMD has the matrix pipe to itself.",
             "`profiles/r3_mfma_rate.md` has the two probes the second kernel was designed from."]
