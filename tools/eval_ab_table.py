@@ -61,7 +61,7 @@ WHAT = {
     "nw4ab1": "nw4, no score passes the filter",
     "twolevel": "shipped kernel + a second threshold level left by every compaction (a histogram bucket edge near rank 3k/4 with its count; appends at or above it are counted and it becomes the threshold once k entries reach it) -- `tools/experiments/eval_two_level.patch`",
     "head": "shipped kernel with a tile's first block staged two tiles ahead into buffers of its own, so that the last block of a tile refills its operand registers from the next tile's first block and no tile starts with fragment reads; two tile loads per block (all landed long before the tile's end) -- `tools/experiments/eval_head_buffers.patch`",
-    "head2": "the same",
+    "head2": "head (two tile loads per block)",
     "head1": "the same with one tile load per block",
     "baseab1": "shipped kernel, no score passes the filter",
     "head2ab1": "head2, no score passes the filter",
