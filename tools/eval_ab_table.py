@@ -66,6 +66,8 @@ WHAT = {
     "baseab1": "shipped kernel, no score passes the filter",
     "head2ab1": "head2, no score passes the filter",
     "head1ab1": "head1, no score passes the filter",
+    "ring4": "shipped kernel with the per-tile barrier replaced by a ring of four tiles of 128 items guarded by counters in LDS (a tile staged two ahead in the first block of a tile, signalled in its last block; a wave may run one tile ahead of the slowest) -- `tools/experiments/eval_ring4.patch`",
+    "ring4ab1": "ring4, no score passes the filter",
     "pp64": "glds, and the second kernel for d=64 as well (four matrix instructions per phase, tiles of 384 items) -- `-DTF_EVAL_PP=2`",
 }
 
@@ -125,6 +127,9 @@ def main():
             "Taking the first fragment reads of a tile and the wait for the last tile load off the path after the barrier (head buffers) is 1-2 % SLOWER",
             "even with no score passing: those cycles are not what holds the tile period above the pipe's time -- the two waves of a SIMD",
             "running unevenly are (`profiles/r3_eval_trace.md`).",
+            "Counters instead of the barrier (ring4): 8 % slower with no score passing (tiles of 128 instead of 256 items: the ring needs four slots), and",
+            "the cost of the pass path shrinks by a tenth only: the younger wave of one SIMD settles exactly one tile behind the others (`gpurun_out/r3_trace_ring.log`),",
+            "i.e. at the limit of the allowed skew, where the counters act like the barrier they replace.",
             "A second threshold level between compactions (fewer appends per scanned item in theory: a tenth to a sixth) changes nothing measurable:",
             "the cycles a wave spends appending are mostly cycles in which the other wave of its SIMD has the matrix pipe to itself.",
             "`profiles/r3_mfma_rate.md` has the two probes the second kernel was designed from."]
