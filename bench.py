@@ -22,6 +22,7 @@ import json
 import os
 import socket
 import subprocess
+import threading
 import sys
 import time
 
@@ -456,6 +457,8 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="testing: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--plain-table", action="store_true", help="single GPU: plain user table (pre-step rows staged per triple) instead of the versioned one")
     ap.add_argument("--no-extras", action="store_true", help="skip the timing of the reference batch size (512 triples per step)")
+    ap.add_argument("--secondary-timeout", type=int, default=480,
+                    help="N > 1: seconds after the headline measurement at which the line is printed without the blocks still running")
     ap.add_argument("--large-scale", type=float, default=1.0, help="testing: shrink the sharded large-shape block (N > 1) by this factor")
     args = ap.parse_args()
 
@@ -615,6 +618,30 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": per_gpu, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per_gpu / HBM_PEAK_GBS,
                                "traffic": None, "kernel": "per GPU: one BPR step incl. the item-gradient exchange",
                                "algorithmic_bytes_per_triple": alg_bytes_per_triple}
+        # Several ranks: the secondary measurements below are collective.  If a rank fails inside one of them (the others then
+        # wait in a collective for ever) or a block outgrows its time, the headline line is not held back: after
+        # --secondary-timeout seconds rank 0 prints what is complete and every rank leaves.
+        emitted = threading.Lock()
+
+        def emit(note=None):
+            if not emitted.acquire(blocking=False):
+                return
+            if rank == 0:
+                line = dict(out)
+                if note:
+                    line["secondary_timeout"] = note
+                print(json.dumps(line), flush=True)
+
+        watchdog = None
+        if world > 1 or args.force_dist:
+            def give_up():
+                emit("secondary measurements stopped after %d s; the blocks present are complete" % args.secondary_timeout)
+                sys.stdout.flush()
+                os._exit(0)
+            watchdog = threading.Timer(args.secondary_timeout + (0 if rank == 0 else 5), give_up)
+            watchdog.daemon = True
+            watchdog.start()
+
         def guarded(name, fn):
             """Secondary measurements must not cost the headline line: a failure is reported in their place."""
             try:
@@ -810,8 +837,9 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(U, I, d, 1 << 17, lr, reg)
                 if "eval" in out and "error" not in out["eval"]:
                     out["eval"]["cpu_baseline"] = cpu_baseline_eval(I, d, args.topk)
-        if rank == 0:
-            print(json.dumps(out), flush=True)
+        if watchdog is not None:
+            watchdog.cancel()
+        emit()
     if world > 1 or args.force_dist:
         torch.distributed.destroy_process_group()
 
