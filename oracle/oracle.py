@@ -205,14 +205,19 @@ def sample_negatives(indptr, indices, n_users, n_items, n_neg, seed, stream, fir
     return users, pos, neg, int(full)
 
 
-def shuffle_perm(n, seed, stream):
-    """CPU statement of tfrec_shuffle_perm: stable argsort of the 64-bit hash keys."""
+def shuffle_keys(n, seed, stream):
+    """The 64-bit hash keys tfrec_shuffle_perm orders the elements by."""
     L = lib()
     L.oracle_shuffle_keys.restype = None
     L.oracle_shuffle_keys.argtypes = [C.c_int64, C.c_uint64, C.c_uint64, np.ctypeslib.ndpointer(np.uint64, flags="C")]
     keys = np.empty(n, np.uint64)
     L.oracle_shuffle_keys(n, seed, stream, keys)
-    return np.argsort(keys, kind="stable").astype(np.int32)
+    return keys
+
+
+def shuffle_perm(n, seed, stream):
+    """CPU statement of tfrec_shuffle_perm: stable argsort of the 64-bit hash keys."""
+    return np.argsort(shuffle_keys(n, seed, stream), kind="stable").astype(np.int32)
 
 
 def csr_to_user_dict(csr):

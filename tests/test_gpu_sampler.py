@@ -51,12 +51,16 @@ def test_ml100k_epoch_equals_the_oracle_and_full_rows_are_reported(dev, oracle, 
     dev.synchronize()
 
 
-@pytest.mark.parametrize("n", [1, 63, 4097, 300000])
+@pytest.mark.parametrize("n", [1, 2, 63, 4097, 300000, 3000000])
 def test_shuffle_and_gather_equal_the_oracle(dev, oracle, n):
     perm = dev.shuffle_perm(n, 77, 5)
     dev.synchronize()
     want = oracle.shuffle_perm(n, 77, 5)
     assert np.array_equal(perm.numpy(), want)
+    if n >= 3000000:
+        # the library sorts by the high key word and orders equal high words afterwards: this size has hundreds of them
+        hi = np.sort(oracle.shuffle_keys(n, 77, 5) >> np.uint64(32))
+        assert int((hi[1:] == hi[:-1]).sum()) > 100
     src = np.arange(3 * n, dtype=np.int32).reshape(n, 3) * 7
     out = dev.gather_rows_i32(dev.array(src, np.int32), perm)
     dev.synchronize()

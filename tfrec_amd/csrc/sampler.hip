@@ -91,25 +91,48 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(const int64_t *__
     }
 }
 
-// The shuffle orders the elements by a 64-bit hash key in two stable 32-bit sorts: by the low word first, then by
-// the high word.  (With 32-bit keys alone about n*n / 2^33 pairs would tie -- a million at 10^8 elements -- and keep
-// their storage order; 64-bit keys tie about n*n / 2^65 times.)
-__global__ __launch_bounds__(256) void shuffle_keys_lo_kernel(int64_t n, uint64_t seed, uint64_t stream, uint32_t *__restrict__ keys,
+// The shuffle orders the elements by a 64-bit hash key, equal keys in storage order.  (With 32-bit keys alone about
+// n*n / 2^33 pairs would tie -- a million at 10^8 elements -- and keep their storage order; 64-bit keys tie about
+// n*n / 2^65 times.)  One stable sort by the high word does almost all of it: what is left are the few runs of equal
+// high words, which a second kernel orders by the low word (then by element, the order the stable sort left them in).
+__device__ __forceinline__ uint64_t shuffle_key(uint64_t seed, uint64_t stream, uint64_t t)
+{
+    return draw64(seed, stream ^ 0x73687566666c65ull, t, 0);
+}
+
+__global__ __launch_bounds__(256) void shuffle_keys_hi_kernel(int64_t n, uint64_t seed, uint64_t stream, uint32_t *__restrict__ keys,
                                                               uint32_t *__restrict__ vals)
 {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
-    keys[t] = (uint32_t)draw64(seed, stream ^ 0x73687566666c65ull, (uint64_t)t, 0);
+    keys[t] = (uint32_t)(shuffle_key(seed, stream, (uint64_t)t) >> 32);
     vals[t] = (uint32_t)t;
 }
 
-// high key words of the elements in the order the first sort left them
-__global__ __launch_bounds__(256) void shuffle_keys_hi_kernel(int64_t n, uint64_t seed, uint64_t stream, const uint32_t *__restrict__ vals,
-                                                              uint32_t *__restrict__ keys)
+// hi: the sorted high words; perm: the elements in that order.  The thread at the first position of a run of equal
+// high words orders the run (insertion sort: runs are two or three elements long) by (low word, element).
+__global__ __launch_bounds__(256) void shuffle_fix_ties_kernel(int64_t n, uint64_t seed, uint64_t stream, const uint32_t *__restrict__ hi,
+                                                               uint32_t *__restrict__ perm)
 {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n) return;
-    keys[t] = (uint32_t)(draw64(seed, stream ^ 0x73687566666c65ull, (uint64_t)vals[t], 0) >> 32);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i + 1 >= n) return;
+    const uint32_t k = hi[i];
+    if (hi[i + 1] != k || (i > 0 && hi[i - 1] == k)) return;
+    int64_t end = i + 2;
+    while (end < n && hi[end] == k) ++end;
+    for (int64_t a = i + 1; a < end; ++a) {
+        const uint32_t e = perm[a];
+        const uint32_t lo = (uint32_t)shuffle_key(seed, stream, (uint64_t)e);
+        int64_t b = a;
+        while (b > i) {
+            const uint32_t f = perm[b - 1];
+            const uint32_t flo = (uint32_t)shuffle_key(seed, stream, (uint64_t)f);
+            if (flo < lo || (flo == lo && f < e)) break;
+            perm[b] = f;
+            --b;
+        }
+        perm[b] = e;
+    }
 }
 
 __global__ __launch_bounds__(256) void gather_rows_i32_kernel(const int32_t *__restrict__ src, const int32_t *__restrict__ perm, int64_t n,
@@ -148,19 +171,19 @@ extern "C" int tfrec_shuffle_perm(tfrec_ctx *ctx, int64_t n, uint64_t seed, uint
     if (n == 0) return TFREC_OK;
     TF_REQUIRE(d_perm_out != nullptr, TFREC_EINVAL, "null output");
     const size_t sort_bytes = tfrec_sort_temp_bytes((size_t)n, 32);
-    TF_TRY(tfrec_ws_require(ctx, ctx->ws_used + 4 * tf_align(4 * (size_t)n) + tf_align(sort_bytes) + 1024));
+    TF_TRY(tfrec_ws_require(ctx, ctx->ws_used + 3 * tf_align(4 * (size_t)n) + tf_align(sort_bytes) + 1024));
     uint32_t *keys = (uint32_t *)tfrec_ws_take(ctx, 4 * (size_t)n), *vals = (uint32_t *)tfrec_ws_take(ctx, 4 * (size_t)n);
-    uint32_t *keys_sorted = (uint32_t *)tfrec_ws_take(ctx, 4 * (size_t)n), *vals_lo = (uint32_t *)tfrec_ws_take(ctx, 4 * (size_t)n);
+    uint32_t *keys_sorted = (uint32_t *)tfrec_ws_take(ctx, 4 * (size_t)n);
     void *tmp = tfrec_ws_take(ctx, sort_bytes);
     TF_REQUIRE(tmp != nullptr, TFREC_ENOMEM, "internal: workspace carve failed");
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    shuffle_keys_lo_kernel<<<blocks, 256, 0, ctx->stream>>>(n, seed, stream, keys, vals);
+    shuffle_keys_hi_kernel<<<blocks, 256, 0, ctx->stream>>>(n, seed, stream, keys, vals);
     TF_HIP(hipGetLastError());
-    TF_TRY(tfrec_sort_pairs(tmp, sort_bytes, keys, keys_sorted, vals, vals_lo, (size_t)n, 32, ctx->stream));
-    shuffle_keys_hi_kernel<<<blocks, 256, 0, ctx->stream>>>(n, seed, stream, vals_lo, keys);
+    // the sort is stable: equal high words keep their storage order, which is the order the tie kernel starts from
+    TF_TRY(tfrec_sort_pairs(tmp, sort_bytes, keys, keys_sorted, vals, reinterpret_cast<uint32_t *>(d_perm_out), (size_t)n, 32, ctx->stream));
+    shuffle_fix_ties_kernel<<<blocks, 256, 0, ctx->stream>>>(n, seed, stream, keys_sorted, reinterpret_cast<uint32_t *>(d_perm_out));
     TF_HIP(hipGetLastError());
-    // equal 64-bit keys keep their original order (both sorts are stable), so the permutation is a function of (seed, stream, n)
-    return tfrec_sort_pairs(tmp, sort_bytes, keys, keys_sorted, vals_lo, reinterpret_cast<uint32_t *>(d_perm_out), (size_t)n, 32, ctx->stream);
+    return TFREC_OK;
 }
 
 extern "C" int tfrec_gather_rows_i32(tfrec_ctx *ctx, const int32_t *d_src, int64_t n_src, const int32_t *d_perm, int64_t n, int width,
