@@ -139,14 +139,10 @@ def other_paths(dev, P, Q, b, U, I, d, B, gen, cuda, steps=10, epoch_pipeline=Tr
     nnz = U * deg
     indptr = torch.arange(0, nnz + 1, deg, device=cuda, dtype=torch.int64)
     indices = torch.sort(torch.randint(0, I, (U, deg), device=cuda, generator=gen, dtype=torch.int32), dim=1).values.reshape(-1).contiguous()
-    eu, ep, en = (torch.empty(nnz, device=cuda, dtype=torch.int32) for _ in range(3))
     su, sp, sn = (torch.empty(nnz, device=cuda, dtype=torch.int32) for _ in range(3))
-    perm = torch.empty(nnz, device=cuda, dtype=torch.int32)
 
     def epoch(e):
-        dev.sample_negatives(indptr, indices, U, I, 1, 2018, 2 * e, users_out=eu, pos_out=ep, neg_out=en)
-        dev.shuffle_perm(nnz, 2018, 2 * e + 1, out=perm)
-        dev.gather_rows_i32(eu, perm, out=su); dev.gather_rows_i32(ep, perm, out=sp); dev.gather_rows_i32(en, perm, out=sn)
+        dev.epoch_triples(indptr, indices, U, I, 2018, 2 * e, 2 * e + 1, users_out=su, pos_out=sp, neg_out=sn)
     epoch(0)
     torch.cuda.synchronize()
     e0.record()
@@ -155,7 +151,7 @@ def other_paths(dev, P, Q, b, U, I, d, B, gen, cuda, steps=10, epoch_pipeline=Tr
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 3
     out["device_epoch_pipeline"] = {"triples_per_s": nnz / (ms * 1e-3), "ms_per_epoch": ms, "interactions": nnz,
-                                    "note": "sample + shuffle + gather of one epoch; the host sampler of the reference is O(items) per user on one core"}
+                                    "note": "tfrec_epoch_triples: sample + shuffle + gather of one epoch; the host sampler of the reference is O(items) per user on one core"}
     # one whole epoch of model/BPR.py:64-72 on the device: draw + shuffle + gather, then every step of the epoch
     # (batches of B triples, the last one short), on a versioned user table with the index of the next batch sorted ahead
     Pe, Qe, be_ = P.clone(), Q.clone(), b.clone()

@@ -118,8 +118,16 @@ int tfrec_sample_negatives(tfrec_ctx *ctx, const int64_t *d_indptr, const int32_
                            int64_t first_interaction,
                            int32_t *d_users_out, int32_t *d_pos_out, int32_t *d_neg_out);
 /* A permutation of 0..n-1 that is a pure function of (seed, stream, n): stable sort by 64-bit hash
- * keys, as two 32-bit sorts (the shuffle of data/dataiterator.py:52-54). */
+ * keys, equal keys in storage order (the shuffle of data/dataiterator.py:52-54). */
 int tfrec_shuffle_perm(tfrec_ctx *ctx, int64_t n, uint64_t seed, uint64_t stream, int32_t *d_perm_out);
+/* One whole epoch of BPR triples, drawn and shuffled (model/BPR.py:50-62 + data/dataiterator.py:52-54 in one call):
+ * exactly what tfrec_sample_negatives(n_neg = 1, stream = draw_stream), tfrec_shuffle_perm(nnz, seed, shuffle_stream)
+ * and three tfrec_gather_rows_i32 produce, with the draws kept as one 16-byte record per interaction in between, so
+ * that the shuffle moves every interaction with one read instead of three.  Outputs: int32 [nnz] each. */
+int tfrec_epoch_triples(tfrec_ctx *ctx, const int64_t *d_indptr, const int32_t *d_indices,
+                        int64_t U, int64_t I, int64_t nnz, uint64_t seed, uint64_t draw_stream, uint64_t shuffle_stream,
+                        int64_t first_interaction,
+                        int32_t *d_users_out, int32_t *d_pos_out, int32_t *d_neg_out);
 /* dst[r, :] = src[perm[r], :] for rows of `width` int32 (applies a shuffle to index arrays). */
 int tfrec_gather_rows_i32(tfrec_ctx *ctx, const int32_t *d_src, int64_t n_src, const int32_t *d_perm,
                           int64_t n, int width, int32_t *d_dst);

@@ -1,5 +1,5 @@
 """GPU tests of the device epoch pipeline (tfrec_sample_negatives, tfrec_shuffle_perm,
-tfrec_gather_rows_i32) against the CPU oracle: sampled indices and permutations are bit-exact."""
+tfrec_gather_rows_i32, tfrec_epoch_triples) against the CPU oracle: sampled indices and permutations are bit-exact."""
 import numpy as np
 import pytest
 
@@ -29,6 +29,37 @@ def test_sampled_negatives_equal_the_oracle(dev, oracle, U, I, lo, hi, n_neg):
     u, p, n = dev.sample_negatives(dev.array(indptr, np.int64), dev.array(indices, np.int32), U, I, n_neg, 2018, 6)
     dev.synchronize()
     assert np.array_equal(u.numpy(), want[0]) and np.array_equal(p.numpy(), want[1]) and np.array_equal(n.numpy(), want[2])
+
+
+@pytest.mark.parametrize("U,I,lo,hi,first", [(1000, 500, 0, 40, 0), (5000, 20000, 1, 300, 12345), (40, 9, 0, 8, 7), (1, 5, 1, 1, 0)])
+def test_epoch_triples_equal_the_oracle_and_the_three_calls(dev, oracle, U, I, lo, hi, first):
+    """tfrec_epoch_triples (packed draws, one shuffle read per interaction) gives what the oracle's draws under the
+    oracle's permutation give, and what tfrec_sample_negatives + tfrec_shuffle_perm + tfrec_gather_rows_i32 give."""
+    rng = np.random.default_rng(3 * U + I)
+    indptr, indices = _rows(rng, U, I, lo, hi)
+    nnz = len(indices)
+    d_ptr, d_idx = dev.array(indptr, np.int64), dev.array(indices, np.int32)
+    u, p, n = dev.epoch_triples(d_ptr, d_idx, U, I, 31, 8, 9, first_interaction=first)
+    dev.synchronize()
+    wu, wp, wn, _ = oracle.sample_negatives(indptr, indices, U, I, 1, 31, 8, first=first)
+    perm = oracle.shuffle_perm(nnz, 31, 9)
+    assert np.array_equal(u.numpy(), wu[perm]) and np.array_equal(p.numpy(), wp[perm]) and np.array_equal(n.numpy(), wn[perm, 0])
+    su, sp, sn = dev.sample_negatives(d_ptr, d_idx, U, I, 1, 31, 8, first_interaction=first)
+    dperm = dev.shuffle_perm(nnz, 31, 9)
+    for got, src in ((u, su), (p, sp), (n, sn)):
+        assert np.array_equal(got.numpy().reshape(-1), dev.gather_rows_i32(src, dperm).numpy().reshape(-1))
+    dev.synchronize()
+
+
+def test_epoch_triples_of_nothing_and_of_a_full_row(dev):
+    empty = dev.epoch_triples(dev.array(np.zeros(4, np.int64), np.int64), dev.empty(0, np.int32), 3, 5, 1, 0, 1)
+    dev.synchronize()
+    assert all(x.numpy().size == 0 for x in empty)
+    # a user who holds every item: nothing can be drawn, reported at synchronize
+    dev.epoch_triples(dev.array(np.array([0, 2, 6], np.int64), np.int64), dev.array(np.array([1, 3, 0, 1, 2, 3], np.int32), np.int32), 2, 4, 1, 0, 1)
+    with pytest.raises(IndexError):
+        dev.synchronize()
+    dev.synchronize()
 
 
 def test_ml100k_epoch_equals_the_oracle_and_full_rows_are_reported(dev, oracle, golden_ml100k):

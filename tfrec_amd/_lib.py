@@ -47,6 +47,7 @@ SIGNATURES = {
     "tfrec_mf_predict": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _i64, _p]),
     "tfrec_sample_negatives": (_int, [_p, _p, _p, _i64, _i64, _i64, _int, _u64, _u64, _i64, _p, _p, _p]),
     "tfrec_shuffle_perm": (_int, [_p, _i64, _u64, _u64, _p]),
+    "tfrec_epoch_triples": (_int, [_p, _p, _p, _i64, _i64, _i64, _u64, _u64, _u64, _i64, _p, _p, _p]),
     "tfrec_gather_rows_i32": (_int, [_p, _p, _i64, _p, _i64, _int, _p]),
     "tfrec_sort_pairs_u32": (_int, [_p, _p, _p, _p, _p, _i64, _int]),
     "tfrec_bpr_sgd_step": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _i64, _f, _f, _p]),

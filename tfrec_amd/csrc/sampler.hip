@@ -39,13 +39,15 @@ __device__ __forceinline__ bool row_contains(const int32_t *__restrict__ idx, in
 
 constexpr int SAMPLE_TRIES = 64;
 
-// One thread per stored interaction t (CSR order): its user, its positive item, and C negatives.
+// One thread per stored interaction t (CSR order): its user, its positive item, and C negatives -- into three arrays,
+// or (packed_out, C = 1) as one 16-byte record per interaction, which a shuffle then moves with one read instead of three.
 // The user of t is found by a binary search confined to the rows the workgroup's 256 interactions
 // span (two whole-array searches per workgroup, a few steps per thread).
 __global__ __launch_bounds__(256) void sample_negatives_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                                                                int64_t U, uint32_t I, int64_t n, int C, uint64_t seed, uint64_t stream,
                                                                uint64_t first, int32_t *__restrict__ users_out, int32_t *__restrict__ pos_out,
-                                                               int32_t *__restrict__ neg_out, uint32_t *__restrict__ flags)
+                                                               int32_t *__restrict__ neg_out, int4 *__restrict__ packed_out,
+                                                               uint32_t *__restrict__ flags)
 {
     __shared__ int64_t row_range[2];
     const int64_t t0 = (int64_t)blockIdx.x * 256;
@@ -87,7 +89,8 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(const int64_t *__
                 ok = !row_contains(indices, r0, r1, (int32_t)cand);
             }
         }
-        neg_out[slot] = (int32_t)cand;
+        if (packed_out) packed_out[t] = make_int4((int32_t)u, indices[t], (int32_t)cand, 0);      // (one negative per positive)
+        else neg_out[slot] = (int32_t)cand;
     }
 }
 
@@ -147,6 +150,39 @@ __global__ __launch_bounds__(256) void gather_rows_i32_kernel(const int32_t *__r
     dst[e] = src[s * width + w];
 }
 
+// users, pos, neg [r] = the record of interaction perm[r]
+__global__ __launch_bounds__(256) void gather_unpack3_kernel(const int4 *__restrict__ packed, const int32_t *__restrict__ perm, int64_t n,
+                                                             int32_t *__restrict__ users_out, int32_t *__restrict__ pos_out,
+                                                             int32_t *__restrict__ neg_out)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const int4 v = packed[perm[r]];
+    users_out[r] = v.x;
+    pos_out[r] = v.y;
+    neg_out[r] = v.z;
+}
+
+size_t shuffle_ws_bytes(int64_t n) { return 3 * tf_align(4 * (size_t)n) + tf_align(tfrec_sort_temp_bytes((size_t)n, 32)) + 1024; }
+
+// (the caller has entered the context and made sure of shuffle_ws_bytes(n) more bytes of workspace)
+int shuffle_perm_impl(tfrec_ctx *ctx, int64_t n, uint64_t seed, uint64_t stream, int32_t *d_perm_out)
+{
+    const size_t sort_bytes = tfrec_sort_temp_bytes((size_t)n, 32);
+    uint32_t *keys = (uint32_t *)tfrec_ws_take(ctx, 4 * (size_t)n), *vals = (uint32_t *)tfrec_ws_take(ctx, 4 * (size_t)n);
+    uint32_t *keys_sorted = (uint32_t *)tfrec_ws_take(ctx, 4 * (size_t)n);
+    void *tmp = tfrec_ws_take(ctx, sort_bytes);
+    TF_REQUIRE(tmp != nullptr, TFREC_ENOMEM, "internal: workspace carve failed");
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    shuffle_keys_hi_kernel<<<blocks, 256, 0, ctx->stream>>>(n, seed, stream, keys, vals);
+    TF_HIP(hipGetLastError());
+    // the sort is stable: equal high words keep their storage order, which is the order the tie kernel starts from
+    TF_TRY(tfrec_sort_pairs(tmp, sort_bytes, keys, keys_sorted, vals, reinterpret_cast<uint32_t *>(d_perm_out), (size_t)n, 32, ctx->stream));
+    shuffle_fix_ties_kernel<<<blocks, 256, 0, ctx->stream>>>(n, seed, stream, keys_sorted, reinterpret_cast<uint32_t *>(d_perm_out));
+    TF_HIP(hipGetLastError());
+    return TFREC_OK;
+}
+
 }  // namespace
 
 extern "C" int tfrec_sample_negatives(tfrec_ctx *ctx, const int64_t *d_indptr, const int32_t *d_indices, int64_t U, int64_t I,
@@ -159,7 +195,7 @@ extern "C" int tfrec_sample_negatives(tfrec_ctx *ctx, const int64_t *d_indptr, c
     if (nnz == 0) return TFREC_OK;
     TF_REQUIRE(d_indptr && d_indices && d_neg_out, TFREC_EINVAL, "null array");
     sample_negatives_kernel<<<(unsigned)((nnz + 255) / 256), 256, 0, ctx->stream>>>(d_indptr, d_indices, U, (uint32_t)I, nnz, n_neg, seed,
-                                                                                  stream, (uint64_t)first_interaction, d_users_out, d_pos_out, d_neg_out, ctx->d_flags);
+                                                                                  stream, (uint64_t)first_interaction, d_users_out, d_pos_out, d_neg_out, nullptr, ctx->d_flags);
     TF_HIP(hipGetLastError());
     return TFREC_OK;
 }
@@ -170,18 +206,29 @@ extern "C" int tfrec_shuffle_perm(tfrec_ctx *ctx, int64_t n, uint64_t seed, uint
     TF_REQUIRE(n >= 0 && n < (1ll << 31), TFREC_EINVAL, "element count %lld out of range", (long long)n);
     if (n == 0) return TFREC_OK;
     TF_REQUIRE(d_perm_out != nullptr, TFREC_EINVAL, "null output");
-    const size_t sort_bytes = tfrec_sort_temp_bytes((size_t)n, 32);
-    TF_TRY(tfrec_ws_require(ctx, ctx->ws_used + 3 * tf_align(4 * (size_t)n) + tf_align(sort_bytes) + 1024));
-    uint32_t *keys = (uint32_t *)tfrec_ws_take(ctx, 4 * (size_t)n), *vals = (uint32_t *)tfrec_ws_take(ctx, 4 * (size_t)n);
-    uint32_t *keys_sorted = (uint32_t *)tfrec_ws_take(ctx, 4 * (size_t)n);
-    void *tmp = tfrec_ws_take(ctx, sort_bytes);
-    TF_REQUIRE(tmp != nullptr, TFREC_ENOMEM, "internal: workspace carve failed");
-    const unsigned blocks = (unsigned)((n + 255) / 256);
-    shuffle_keys_hi_kernel<<<blocks, 256, 0, ctx->stream>>>(n, seed, stream, keys, vals);
+    TF_TRY(tfrec_ws_require(ctx, ctx->ws_used + shuffle_ws_bytes(n)));
+    return shuffle_perm_impl(ctx, n, seed, stream, d_perm_out);
+}
+
+extern "C" int tfrec_epoch_triples(tfrec_ctx *ctx, const int64_t *d_indptr, const int32_t *d_indices, int64_t U, int64_t I, int64_t nnz,
+                                   uint64_t seed, uint64_t draw_stream, uint64_t shuffle_stream, int64_t first_interaction,
+                                   int32_t *d_users_out, int32_t *d_pos_out, int32_t *d_neg_out)
+{
+    TF_TRY(tfrec_ctx_enter(ctx));
+    TF_REQUIRE(U > 0 && I > 0 && I < (1ll << 31) && U < (1ll << 31), TFREC_EINVAL, "bad shape U=%lld I=%lld", (long long)U, (long long)I);
+    TF_REQUIRE(nnz >= 0 && nnz < (1ll << 31) && first_interaction >= 0, TFREC_EINVAL, "bad interaction count or offset");
+    if (nnz == 0) return TFREC_OK;
+    TF_REQUIRE(d_indptr && d_indices && d_users_out && d_pos_out && d_neg_out, TFREC_EINVAL, "null array");
+    TF_TRY(tfrec_ws_require(ctx, tf_align(16 * (size_t)nnz) + tf_align(4 * (size_t)nnz) + shuffle_ws_bytes(nnz) + 1024));
+    int4 *packed = (int4 *)tfrec_ws_take(ctx, 16 * (size_t)nnz);
+    int32_t *perm = (int32_t *)tfrec_ws_take(ctx, 4 * (size_t)nnz);
+    TF_REQUIRE(perm != nullptr, TFREC_ENOMEM, "internal: workspace carve failed");
+    const unsigned blocks = (unsigned)((nnz + 255) / 256);
+    sample_negatives_kernel<<<blocks, 256, 0, ctx->stream>>>(d_indptr, d_indices, U, (uint32_t)I, nnz, 1, seed, draw_stream,
+                                                            (uint64_t)first_interaction, nullptr, nullptr, nullptr, packed, ctx->d_flags);
     TF_HIP(hipGetLastError());
-    // the sort is stable: equal high words keep their storage order, which is the order the tie kernel starts from
-    TF_TRY(tfrec_sort_pairs(tmp, sort_bytes, keys, keys_sorted, vals, reinterpret_cast<uint32_t *>(d_perm_out), (size_t)n, 32, ctx->stream));
-    shuffle_fix_ties_kernel<<<blocks, 256, 0, ctx->stream>>>(n, seed, stream, keys_sorted, reinterpret_cast<uint32_t *>(d_perm_out));
+    TF_TRY(shuffle_perm_impl(ctx, nnz, seed, shuffle_stream, perm));
+    gather_unpack3_kernel<<<blocks, 256, 0, ctx->stream>>>(packed, perm, nnz, d_users_out, d_pos_out, d_neg_out);
     TF_HIP(hipGetLastError());
     return TFREC_OK;
 }

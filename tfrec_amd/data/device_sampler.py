@@ -26,11 +26,9 @@ class DeviceEpochSampler:
         self.first_interaction = int(first_interaction)    # position of row 0's first interaction in the whole set (row shards)
         self.indptr = dev.array(csr.indptr.astype(np.int64), np.int64)
         self.indices = dev.array(csr.indices.astype(np.int32), np.int32)
-        # outputs in storage order, reused every epoch; shuffled copies are what the steps read
-        self._users = dev.empty(self.nnz, np.int32)
-        self._pos = dev.empty(self.nnz, np.int32)
-        self._neg = dev.empty((self.nnz, self.n_neg), np.int32)
-        self._perm = dev.empty(self.nnz, np.int32)
+        # outputs in storage order (made when first needed: the one-negative epoch never holds them), reused every epoch;
+        # shuffled copies are what the steps read
+        self._users = self._pos = self._neg = self._perm = None
         self.users = dev.empty(self.nnz, np.int32)
         self.pos = dev.empty(self.nnz, np.int32)
         self.neg = dev.empty((self.nnz, self.n_neg), np.int32)
@@ -39,6 +37,16 @@ class DeviceEpochSampler:
         """Device arrays (users, pos, neg) of epoch ``e``: int32 [nnz], [nnz], [nnz, n_neg].
         Streams 2e and 2e+1 of the seed feed the draws and the shuffle."""
         dev = self.dev
+        if shuffle and self.n_neg == 1:
+            # one call: the draws stay packed (user, item, negative) until the shuffle has moved them
+            dev.epoch_triples(self.indptr, self.indices, self.n_users, self.n_items, self.seed, 2 * e, 2 * e + 1,
+                              users_out=self.users, pos_out=self.pos, neg_out=self.neg, first_interaction=self.first_interaction)
+            return self.users, self.pos, self.neg
+        if self._users is None:
+            self._users = dev.empty(self.nnz, np.int32)
+            self._pos = dev.empty(self.nnz, np.int32)
+            self._neg = dev.empty((self.nnz, self.n_neg), np.int32)
+            self._perm = dev.empty(self.nnz, np.int32)
         dev.sample_negatives(self.indptr, self.indices, self.n_users, self.n_items, self.n_neg, self.seed, 2 * e,
                              users_out=self._users, pos_out=self._pos, neg_out=self._neg, first_interaction=self.first_interaction)
         if not shuffle:

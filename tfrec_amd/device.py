@@ -224,6 +224,21 @@ class Device:
                                                    _ptr(users_out), _ptr(pos_out), _ptr(neg_out)))
         return users_out, pos_out, neg_out
 
+    def epoch_triples(self, indptr, indices, n_users, n_items, seed, draw_stream, shuffle_stream, users_out=None, pos_out=None, neg_out=None,
+                      first_interaction=0):
+        """One epoch of BPR triples, drawn (one negative per stored interaction) and shuffled: what ``sample_negatives``,
+        ``shuffle_perm`` and three ``gather_rows_i32`` give, in one call (model/BPR.py:50-62, data/dataiterator.py:52-54).
+        Returns (users, pos, neg), int32 [nnz] each."""
+        nnz = _shape(indices)[0]
+        users_out = users_out if users_out is not None else self.empty(nnz, np.int32)
+        pos_out = pos_out if pos_out is not None else self.empty(nnz, np.int32)
+        neg_out = neg_out if neg_out is not None else self.empty(nnz, np.int32)
+        m = 2 ** 64 - 1
+        _lib.check(self.lib.tfrec_epoch_triples(self.h, _ptr(indptr), _ptr(indices), int(n_users), int(n_items), nnz, int(seed) & m,
+                                                int(draw_stream) & m, int(shuffle_stream) & m, int(first_interaction),
+                                                _ptr(users_out), _ptr(pos_out), _ptr(neg_out)))
+        return users_out, pos_out, neg_out
+
     def shuffle_perm(self, n, seed, stream, out=None):
         """A permutation of range(n), a pure function of (seed, stream, n) (data/dataiterator.py:52-54)."""
         out = out if out is not None else self.empty(n, np.int32)

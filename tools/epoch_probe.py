@@ -24,9 +24,12 @@ perm = torch.empty(nnz, device=cuda, dtype=torch.int32)
 
 
 def epoch(e):
-    dev.sample_negatives(indptr, indices, U, I, 1, 2018, 2 * e, users_out=eu, pos_out=ep, neg_out=en)
-    dev.shuffle_perm(nnz, 2018, 2 * e + 1, out=perm)
-    dev.gather_rows_i32(eu, perm, out=su); dev.gather_rows_i32(ep, perm, out=sp); dev.gather_rows_i32(en, perm, out=sn)
+    if os.environ.get("EPOCH_PROBE_THREE_CALLS"):
+        dev.sample_negatives(indptr, indices, U, I, 1, 2018, 2 * e, users_out=eu, pos_out=ep, neg_out=en)
+        dev.shuffle_perm(nnz, 2018, 2 * e + 1, out=perm)
+        dev.gather_rows_i32(eu, perm, out=su); dev.gather_rows_i32(ep, perm, out=sp); dev.gather_rows_i32(en, perm, out=sn)
+    else:
+        dev.epoch_triples(indptr, indices, U, I, 2018, 2 * e, 2 * e + 1, users_out=su, pos_out=sp, neg_out=sn)
 
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
