@@ -1,5 +1,5 @@
-"""Developer tool: random shapes of tfrec_score_topk against a float64 product (and, with integer-valued factors, against
-the exact ranking including ties).  python tools/eval_fuzz.py [cases] [seed]"""
+"""Not collected by pytest (run by hand on a GPU box): random shapes of tfrec_score_topk against a float64 product (and, with integer-valued factors, against
+the exact ranking including ties).  python tests/fuzz_eval.py [cases] [seed]"""
 import os
 import sys
 import time

@@ -1,0 +1,97 @@
+"""Not collected by pytest (run by hand on a GPU box): random shapes of the BPR step (plain table, versioned table, versioned table with the batch sorted
+ahead; two consecutive steps) against the CPU oracle.  python tests/fuzz_train.py [cases] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle  # noqa: E402
+from tfrec_amd.device import Device  # noqa: E402
+
+
+def zipf_ids(rng, n, size):
+    w = 1.0 / np.arange(1, n + 1)
+    return rng.permutation(n)[rng.choice(n, size=size, p=w / w.sum())]
+
+
+def one(dev, rng, case):
+    d = int(rng.choice([1, 3, 8, 10, 16, 20, 32, 48, 64, 100, 128, 200, 256]))
+    U = int(rng.choice([rng.integers(1, 10), rng.integers(10, 3000), rng.integers(3000, 200000)]))
+    I = int(rng.choice([rng.integers(2, 10), rng.integers(10, 3000), rng.integers(3000, 50000)]))
+    edge = int(rng.choice([16, 64, 256, 4096, 8192, 131072]))
+    B = int(rng.choice([rng.integers(1, 600), edge + rng.integers(-1, 2), rng.integers(600, 20000), rng.integers(100000, 400000)]))
+    if B * d > 3e7 or (U + I) * d > 3e7:
+        d = 16
+    kind = str(rng.choice(["uniform", "zipf", "hot"]))
+    path = str(rng.choice(["plain", "versioned", "prepared"]))
+    P = rng.uniform(-0.3, 0.3, (U, d)).astype(np.float32)
+    Q = rng.uniform(-0.3, 0.3, (I, d)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, I).astype(np.float32)
+    desc = "case %d: %s d=%d U=%d I=%d B=%d %s" % (case, path, d, U, I, B, kind)
+    batches = []
+    for _ in range(2):
+        u = rng.integers(0, U, B).astype(np.int32)
+        if kind == "zipf":
+            i = zipf_ids(rng, I, B).astype(np.int32)
+        elif kind == "hot":
+            i = np.where(rng.random(B) < 0.5, 0, rng.integers(0, I, B)).astype(np.int32)
+            u = np.where(rng.random(B) < 0.3, U - 1, u).astype(np.int32)
+        else:
+            i = rng.integers(0, I, B).astype(np.int32)
+        j = rng.integers(0, I, B).astype(np.int32)
+        batches.append((u, i, j))
+    Po, Qo, bo = P.copy(), Q.copy(), b.copy()
+    losses = [oracle.bpr_step(Po, Qo, bo, *bt, 0.01, 0.05, threads=8) for bt in batches]
+    dP, dQ, db = dev.array(P), dev.array(Q), dev.array(b)
+    dl = [dev.zeros(2, np.float64) for _ in batches]
+    dbt = [tuple(dev.array(x, np.int32) for x in bt) for bt in batches]
+    if path == "plain":
+        for bt, l in zip(dbt, dl):
+            dev.bpr_sgd_step(dP, dQ, db, *bt, 0.01, 0.05, l)
+    else:
+        ut = dev.user_table(dP)
+        if path == "versioned":
+            for bt, l in zip(dbt, dl):
+                dev.bpr_sgd_step_v(ut, dQ, db, *bt, 0.01, 0.05, l)
+        else:
+            dev.prepare_batch(0, U, I, *dbt[0])
+            dev.prepare_batch(1, U, I, *dbt[1])
+            dev.bpr_sgd_step_prepared_v(0, ut, dQ, db, 0.01, 0.05, dl[0])
+            dev.bpr_sgd_step_prepared_v(1, ut, dQ, db, 0.01, 0.05, dl[1])
+        ut.flatten()
+        dev.synchronize()
+        ut.close()
+    dev.synchronize()
+    for name, new, ref, old in (("P", dP.numpy(), Po, P), ("Q", dQ.numpy(), Qo, Q), ("b", db.numpy(), bo, b)):
+        scale = max(np.abs(ref - old).max(), 1e-3)
+        err = np.abs(new - ref).max()
+        if not err <= 2e-5 * scale + 4e-7 * np.abs(ref).max():
+            return desc + ": %s differs by %g (update scale %g)" % (name, err, scale)
+    for l, (rank, regl) in zip(dl, losses):
+        if not np.allclose(l.numpy(), [rank, regl], rtol=2e-5):
+            return desc + ": loss %s vs %s" % (l.numpy(), (rank, regl))
+    return None
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    dev = Device(0)
+    rng = np.random.default_rng(seed)
+    bad, t0 = 0, time.time()
+    for c in range(cases):
+        msg = one(dev, rng, c)
+        if msg:
+            bad += 1
+            print("FAIL", msg, flush=True)
+        if c % 20 == 19:
+            print("%d cases, %d failures, %.0f s" % (c + 1, bad, time.time() - t0), flush=True)
+    print("done: %d cases, %d failures" % (cases, bad), flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
