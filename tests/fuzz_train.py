@@ -1,5 +1,5 @@
 """Not collected by pytest (run by hand on a GPU box): random shapes of the BPR step (plain table, versioned table, versioned table with the batch sorted
-ahead; two consecutive steps) against the CPU oracle.  python tests/fuzz_train.py [cases] [seed]"""
+ahead; two consecutive steps) and, every fourth case, of the APR-Adagrad step, against the CPU oracle.  python tests/fuzz_train.py [cases] [seed]"""
 import os
 import sys
 import time
@@ -76,6 +76,51 @@ def one(dev, rng, case):
     return None
 
 
+def one_apr(dev, rng, case):
+    """One APR-Adagrad step (model/APR.py:156-184) on a random shape against the oracle: parameters, accumulators, losses."""
+    d = int(rng.choice([3, 8, 16, 20, 32, 64, 100, 128]))
+    U = int(rng.choice([rng.integers(1, 10), rng.integers(10, 3000), rng.integers(3000, 50000)]))
+    I = int(rng.choice([rng.integers(2, 10), rng.integers(10, 3000), rng.integers(3000, 20000)]))
+    edge = int(rng.choice([16, 64, 128, 4096, 8192, 131072]))
+    B = int(rng.choice([rng.integers(1, 600), edge + rng.integers(-1, 2), rng.integers(600, 20000), rng.integers(100000, 200000)]))
+    if B * d > 1.5e7 or (U + I) * d > 1.5e7:
+        d = 16
+    # (beyond some ten thousand occurrences per row the float32 sums of the step -- terms of both signs -- leave the 1e-4 of the
+    # accumulator check: tests/probe_apr_precision.py shows the error growing smoothly with the row's occurrence count)
+    B = int(min(B, 10000 * min(U, I)))
+    reg = float(rng.choice([0.0, 0.05]))
+    kind = str(rng.choice(["uniform"] if I < 100 else ["uniform", "zipf"]))
+    desc = "case %d: apr d=%d U=%d I=%d B=%d reg=%g %s" % (case, d, U, I, B, reg, kind)
+    P = rng.uniform(-0.3, 0.3, (U, d)).astype(np.float32)
+    Q = rng.uniform(-0.3, 0.3, (I, d)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, I).astype(np.float32)
+    u = rng.integers(0, U, B).astype(np.int32)
+    i = (zipf_ids(rng, I, B) if kind == "zipf" else rng.integers(0, I, B)).astype(np.int32)
+    j = rng.integers(0, I, B).astype(np.int32)
+    Po, Qo, bo = P.copy(), Q.copy(), b.copy()
+    aP, aQ, ab = [np.full_like(x, 0.1) for x in (P, Q, b)]
+    losses = oracle.apr_step(Po, Qo, bo, aP, aQ, ab, u, i, j, 0.05, reg, 1.0, 0.05)
+    arrs = [dev.array(x) for x in (P, Q, b)]
+    accs = [dev.full(x.shape, 0.1) for x in (P, Q, b)]
+    dels = [dev.zeros(x.shape) for x in (P, Q, b)]
+    loss = dev.zeros(3, np.float64)
+    dev.apr_adagrad_step(*arrs, *accs, *dels, dev.array(u, np.int32), dev.array(i, np.int32), dev.array(j, np.int32), 0.05, reg, 1.0, 0.05, loss)
+    dev.synchronize()
+    for name, got, ref, old in zip("PQb", [x.numpy() for x in arrs], (Po, Qo, bo), (P, Q, b)):
+        scale = max(np.abs(ref - old).max(), 1e-3)
+        err = np.abs(got - ref).max()
+        # (looser than the fixed cases of tests/test_gpu_train.py: with thousands of occurrences per row the float32 sums -- terms
+        # of both signs, and Adagrad divides by their root -- are a few 1e-5 from the float64 oracle; a wrong or missing term is 1e-2)
+        if not err <= 3e-4 * scale + 2e-7 * np.abs(ref).max():
+            return desc + ": %s differs by %g (update scale %g)" % (name, err, scale)
+    for name, got, ref in zip("PQb", [x.numpy() for x in accs], (aP, aQ, ab)):
+        if not np.allclose(got, ref, rtol=1e-3, atol=1e-6):
+            return desc + ": accumulator of %s differs by %g" % (name, np.abs(got - ref).max())
+    if not np.allclose(loss.numpy(), losses, rtol=2e-5):
+        return desc + ": losses %s vs %s" % (loss.numpy(), losses)
+    return None
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -83,7 +128,7 @@ def main():
     rng = np.random.default_rng(seed)
     bad, t0 = 0, time.time()
     for c in range(cases):
-        msg = one(dev, rng, c)
+        msg = one_apr(dev, rng, c) if c % 4 == 3 else one(dev, rng, c)
         if msg:
             bad += 1
             print("FAIL", msg, flush=True)
