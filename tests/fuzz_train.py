@@ -1,5 +1,5 @@
 """Not collected by pytest (run by hand on a GPU box): random shapes of the BPR step (plain table, versioned table, versioned table with the batch sorted
-ahead; two consecutive steps) and, every fourth case, of the APR-Adagrad step, against the CPU oracle.  python tests/fuzz_train.py [cases] [seed]"""
+ahead; two consecutive steps) of the APR-Adagrad step, of the DNS selection and of the epoch draw, against the CPU oracle.  python tests/fuzz_train.py [cases] [seed]"""
 import os
 import sys
 import time
@@ -121,6 +121,45 @@ def one_apr(dev, rng, case):
     return None
 
 
+def one_dns(dev, rng, case):
+    """tfrec_dns_select (model/DNSBPR.py:65-80) on a random shape: the best-scored candidate of every pool, first maximum wins."""
+    d = int(rng.choice([1, 8, 10, 16, 20, 32, 64, 100, 128, 256]))
+    U, I = int(rng.integers(1, 3000)), int(rng.integers(2, 20000))
+    n, C = int(rng.integers(1, 20000)), int(rng.choice([1, 2, 7, 15, 16, 32, 33, 64]))
+    P = rng.uniform(-0.3, 0.3, (U, d)).astype(np.float32)
+    Q = rng.uniform(-0.3, 0.3, (I, d)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, I).astype(np.float32)
+    users = rng.integers(0, U, n).astype(np.int32)
+    pool = rng.integers(0, I, (n, C)).astype(np.int32)
+    got = dev.dns_select(dev.array(P), dev.array(Q), dev.array(b), dev.array(users, np.int32), dev.array(pool, np.int32)).numpy()
+    dev.synchronize()
+    ref, margin = oracle.dns_select(P, Q, b, users, pool)
+    ok = margin > 1e-5
+    desc = "case %d: dns d=%d U=%d I=%d n=%d C=%d" % (case, d, U, I, n, C)
+    if not np.array_equal(got[ok], ref[ok]):
+        return desc + ": picks differ where the margin is clear"
+    if not (pool == got[:, None]).any(axis=1).all():
+        return desc + ": a pick is not one of its pool's candidates"
+    return None
+
+
+def one_epoch(dev, rng, case):
+    """tfrec_epoch_triples on a random training matrix: the oracle's draws under the oracle's permutation, bit for bit."""
+    U, I = int(rng.integers(1, 5000)), int(rng.integers(2, 30000))
+    hi = int(min(rng.choice([1, 5, 40, 300]), I - 1))
+    lens = rng.integers(0, hi + 1, U)
+    indptr = np.zeros(U + 1, np.int64); indptr[1:] = np.cumsum(lens)
+    indices = np.concatenate([np.sort(rng.choice(I, m, replace=False)) for m in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
+    seed, st, first = int(rng.integers(0, 2 ** 31)), int(rng.integers(0, 1000)), int(rng.choice([0, rng.integers(0, 10 ** 9)]))
+    u, p, n = dev.epoch_triples(dev.array(indptr, np.int64), dev.array(indices, np.int32), U, I, seed, 2 * st, 2 * st + 1, first_interaction=first)
+    dev.synchronize()
+    wu, wp, wn, _ = oracle.sample_negatives(indptr, indices, U, I, 1, seed, 2 * st, first=first)
+    perm = oracle.shuffle_perm(len(indices), seed, 2 * st + 1)
+    if not (np.array_equal(u.numpy(), wu[perm]) and np.array_equal(p.numpy(), wp[perm]) and np.array_equal(n.numpy().reshape(-1), wn[perm, 0])):
+        return "case %d: epoch U=%d I=%d nnz=%d: triples differ from the oracle's" % (case, U, I, len(indices))
+    return None
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -128,7 +167,7 @@ def main():
     rng = np.random.default_rng(seed)
     bad, t0 = 0, time.time()
     for c in range(cases):
-        msg = one_apr(dev, rng, c) if c % 4 == 3 else one(dev, rng, c)
+        msg = (one, one, one_dns, one_apr, one, one_epoch)[c % 6](dev, rng, c)
         if msg:
             bad += 1
             print("FAIL", msg, flush=True)
