@@ -1,5 +1,5 @@
 """Not collected by pytest (run by hand on a GPU box): random shapes of tfrec_score_topk against a float64 product (and, with integer-valued factors, against
-the exact ranking including ties).  python tests/fuzz_eval.py [cases] [seed]"""
+the exact ranking including ties); every fifth case the whole evaluation (lists and metric curves) against the oracle.  python tests/fuzz_eval.py [cases] [seed]"""
 import os
 import sys
 import time
@@ -94,6 +94,48 @@ def one(dev, rng, case):
     return None
 
 
+def one_metrics(dev, rng, case):
+    """tfrec_eval_fullrank in f32 with the reference's float32 means (evaluator/backend/cpp/include/evaluate.h) on a random
+    shape against the oracle: rank lists and the 5 x k metric curves bit for bit."""
+    from oracle import oracle
+    d = int(rng.choice([1, 8, 16, 20, 32, 64, 100, 128]))
+    U, I = int(rng.integers(1, 1500)), int(rng.integers(260, 8000))
+    k = int(rng.choice([1, 5, 10, 50, 100, 200]))
+    n = int(rng.integers(1, U + 1))
+    if rng.random() < 0.5:
+        P = rng.integers(-2, 3, (U, d)).astype(np.float32); Q = rng.integers(-2, 3, (I, d)).astype(np.float32)
+        b = rng.integers(-3, 4, I).astype(np.float32)
+    else:
+        P = rng.uniform(-0.5, 0.5, (U, d)).astype(np.float32); Q = rng.uniform(-0.5, 0.5, (I, d)).astype(np.float32)
+        b = rng.normal(0, 0.1, I).astype(np.float32)
+    def rows(max_len, min_len=0):
+        lens = rng.integers(min_len, max_len + 1, U)
+        ptr = np.zeros(U + 1, np.int64); ptr[1:] = np.cumsum(lens)
+        idx = np.concatenate([np.sort(rng.choice(I, m, replace=False)) for m in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
+        return ptr, idx
+    tr, te = rows(int(rng.choice([0, 5, 50]))), rows(int(rng.choice([1, 3, 30])))
+    # the evaluated users are users with test items (evaluator/abstract_evaluator.py keeps no others)
+    have = np.flatnonzero(np.diff(te[0]) > 0)
+    if len(have) == 0:
+        return None
+    users = np.sort(rng.choice(have, min(n, len(have)), replace=False)).astype(np.int32)
+    n = len(users)
+    ids = dev.empty((n, k), np.int32)
+    m = dev.eval_fullrank(dev.array(P), dev.array(Q), dev.array(b), dev.array(users), (dev.array(tr[0], np.int64), dev.array(tr[1], np.int32)),
+                          (dev.array(te[0], np.int64), dev.array(te[1], np.int32)), k, mode=SCORE_F32, mean_mode=1, out_ids=ids)
+    mean, rank, _ = oracle.eval_fullrank(P, Q, b, users, tr, te, k, score_mode=1)      # the float32 chain the f32 kernel computes
+    desc = "case %d: metrics d=%d U=%d n=%d I=%d k=%d" % (case, d, U, n, I, k)
+    if not np.array_equal(ids.numpy(), rank):
+        r, c = np.argwhere(ids.numpy() != rank)[0]
+        g, w = int(ids.numpy()[r, c]), int(rank[r, c])
+        sg, sw = [float(np.float32(P[users[r]].astype(np.float64) @ Q[x].astype(np.float64) + b[x])) for x in (g, w)]
+        return desc + ": rank lists differ from the oracle's at row %d rank %d: %d (score %.9g) vs %d (score %.9g), %d entries in all" % (
+            r, c, g, sg, w, sw, int((ids.numpy() != rank).sum()))
+    if not np.array_equal(np.asarray(m), mean, equal_nan=True):
+        return desc + ": metric curves differ by %g" % np.abs(np.asarray(m) - mean).max()
+    return None
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -102,7 +144,7 @@ def main():
     bad = 0
     t0 = time.time()
     for c in range(cases):
-        msg = one(dev, rng, c)
+        msg = one_metrics(dev, rng, c) if c % 5 == 4 else one(dev, rng, c)
         if msg:
             bad += 1
             print("FAIL", msg, flush=True)
