@@ -58,6 +58,28 @@ def test_single_rank_sharded_path_matches_unsharded(oracle, item_mode):
     dev.close()
 
 
+@pytest.mark.parametrize("item_mode", ["sharded", "dense"])
+@pytest.mark.parametrize("U,I,d,sizes", [(1, 1, 4, [0, 1, 0, 3]), (3, 2, 8, [0, 0, 5]), (50, 40, 64, [0, 7, 0]), (2, 300, 16, [1, 0, 2])])
+def test_empty_and_tiny_batches_on_tiny_tables(item_mode, U, I, d, sizes):
+    """A rank's part of a batch may be empty (its users drew nothing) and tables may have a single row: the sharded step
+    then does nothing, or what the plain step does."""
+    from tfrec_amd.sharded import ShardedBprTrainer, make_device
+    dev = make_device(0)
+    cuda = torch.device("cuda", 0)
+    rng = np.random.default_rng(U + I)
+    tr = ShardedBprTrainer(dev, U, I, d, 0.01, 0.05, seed=2018, item_mode=item_mode)
+    P0, Q0, b0 = [x.clone() for x in (tr.P, tr.Q, tr.b)]
+    for B in sizes:
+        u, i, j = [torch.from_numpy(rng.integers(0, n, B).astype(np.int32)).to(cuda) for n in (U, I, I)]
+        tr.step(u, i, j)
+        if B:
+            dev.bpr_sgd_step(P0, Q0, b0, u, i, j, 0.01, 0.05)
+    dev.synchronize()
+    for a, c in ((tr.P, P0), (tr.Q, Q0), (tr.b, b0)):
+        np.testing.assert_allclose(a.cpu().numpy(), c.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    dev.close()
+
+
 @pytest.mark.parametrize("K", [2, 5, 32])
 def test_item_half_in_ranges_of_item_ids_equals_the_whole(K):
     """The replicated-table step with its item half cut into K ranges of item ids (what the overlapped all-reduce
