@@ -608,6 +608,11 @@ struct ScoreGeom {
 #ifndef TF_EVAL_APPROX_SELECT
 #define TF_EVAL_APPROX_SELECT 1
 #endif
+// a list half is compacted when fewer than this many free entries are left (16 = the most a lane appends per block:
+// as late as possible; more = earlier compactions, tighter thresholds)
+#ifndef TF_EVAL_TRIGGER_SLACK
+#define TF_EVAL_TRIGGER_SLACK 16
+#endif
 
 template <int D, bool BF16, int CAP>
 __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk_kernel(ScoreArgs a)
@@ -791,7 +796,7 @@ __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk
                 TF_PROF_ADD(1, prof_t_ins);
                 // a list that could overflow during the next 32 items is compacted now
                 // (a lane adds at most its 16 items of a block of 32 to its half)
-                uint64_t need = __ballot(mycnt[s] > CAP / 2 - 16);
+                uint64_t need = __ballot(mycnt[s] > CAP / 2 - TF_EVAL_TRIGGER_SLACK);
                 need = (need | (need >> 32)) & 0xffffffffull;          // by user
                 [[maybe_unused]] const unsigned long long prof_t_cmp = TF_PROF_T();
                 while (need) {
@@ -1021,7 +1026,7 @@ __global__ __launch_bounds__(512) void score_topk_pp_kernel(ScoreArgs a)
                 }
             }
         }
-        uint64_t need = __ballot(mycnt[S] > CAP / 2 - 16);
+        uint64_t need = __ballot(mycnt[S] > CAP / 2 - TF_EVAL_TRIGGER_SLACK);
         need = (need | (need >> 32)) & 0xffffffffull;          // by user
         TF_PROF_ADD(14, prof_t_ins);
         [[maybe_unused]] const unsigned long long prof_t_cmp = TF_PROF_T();

@@ -68,6 +68,9 @@ WHAT = {
     "head1ab1": "head1, no score passes the filter",
     "ring4": "shipped kernel with the per-tile barrier replaced by a ring of four tiles of 128 items guarded by counters in LDS (a tile staged two ahead in the first block of a tile, signalled in its last block; a wave may run one tile ahead of the slowest) -- `tools/experiments/eval_ring4.patch`",
     "ring4ab1": "ring4, no score passes the filter",
+    "trig32": "shipped kernels, a list half compacted when fewer than 32 (instead of 16) entries are free -- `-DTF_EVAL_TRIGGER_SLACK=32`",
+    "trig48": "the same, 48",
+    "trig64": "the same, 64",
     "pp64": "glds, and the second kernel for d=64 as well (four matrix instructions per phase, tiles of 384 items) -- `-DTF_EVAL_PP=2`",
 }
 
@@ -130,6 +133,9 @@ def main():
             "Counters instead of the barrier (ring4): 8 % slower with no score passing (tiles of 128 instead of 256 items: the ring needs four slots), and",
             "the cost of the pass path shrinks by a tenth only: the younger wave of one SIMD settles exactly one tile behind the others (`gpurun_out/r3_trace_ring.log`),",
             "i.e. at the limit of the allowed skew, where the counters act like the barrier they replace.",
+            "Earlier compactions (`-DTF_EVAL_TRIGGER_SLACK`): with k=100 in lists of 256 every earlier trigger loses (lists are 100 + train-row entries long",
+            "after a compaction: there is no room to give away); with k=50 (C2 shape, `tools/ab_eval_c2.sh`) a slack of 64 gives 11.6 against 12.1 ms with independent",
+            "factors and 9.6 against 9.4 ms with biased ones, with k=10 9.8 / 8.2 against 10.4 / 8.3 ms; 72 and more lose everywhere.  Not changed.",
             "A second threshold level between compactions (fewer appends per scanned item in theory: a tenth to a sixth) changes nothing measurable:",
             "the cycles a wave spends appending are mostly cycles in which the other wave of its SIMD has the matrix pipe to itself.",
             "`profiles/r3_mfma_rate.md` has the two probes the second kernel was designed from."]
