@@ -348,7 +348,7 @@ def test_masked_items_at_the_top_of_every_ranking(dev, k, deg):
 
 @pytest.mark.parametrize("mode_name", ["f32", "bf16"])
 @pytest.mark.parametrize("d", [8, 20, 32, 48, 64, 100, 128, 200, 256])
-@pytest.mark.parametrize("k", [1, 50, 113, 240])
+@pytest.mark.parametrize("k", [1, 50, 100, 113, 240])
 def test_every_kernel_instantiation(dev, mode_name, d, k):
     """Every (padded factor size, list capacity, score mode) instantiation of the scoring kernel -- they differ in
     waves per workgroup, tile length and registers -- on a user count that leaves waves and workgroups partly

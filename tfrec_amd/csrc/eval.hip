@@ -487,7 +487,7 @@ __device__ __forceinline__ int wave_finish(const uint64_t *__restrict__ list, in
                                            const int32_t *__restrict__ mask_idx, int64_t mlo, int64_t mhi,
                                            volatile uint64_t *sortbuf, int lane)
 {
-    constexpr int SN = CAP / 2;               // k <= CAP/2 - 16 for every capacity in use
+    constexpr int SN = (CAP / 2 & (CAP / 2 - 1)) == 0 ? CAP / 2 : 128;     // a power of two (the sort); k <= SN - 16 for every capacity in use
     float tau;
     // a list that fits the sort as it is needs no selection first (asking for more survivors than it can
     // hold makes the selection keep every unmasked entry); the sort then puts the best k in front
@@ -905,7 +905,7 @@ struct PpGeom {
     static constexpr int ROWB = D * 2;                       // LDS rows are not padded (see load_rows)
     static constexpr int CPR = ROWB / 16, RPI = 1024 / ROWB; // 16-byte chunks per row; rows per direct-to-LDS instruction of a wave
     // items per tile: as many as fit twice beside the sort buffers, a divisor of the item-split granularity (768)
-    static constexpr int TI = D == 128 ? (CAP <= 256 ? TF_EVAL_PP_TI : 192) : 384, NB = TI / 32;   // and blocks per tile
+    static constexpr int TI = D == 128 ? (CAP <= 384 ? TF_EVAL_PP_TI : 192) : 384, NB = TI / 32;   // and blocks per tile
     static constexpr int IPW = TI / (RPI * NW), BPI = NB / IPW;             // load instructions per wave and tile; blocks per instruction
     static_assert(KS == 8 || KS == 4, "the interleaving below is written for eight or four matrix instructions per phase");
     static_assert(NB >= 2 && IPW * RPI * NW == TI && BPI * IPW == NB && NT >= TI && 768 % TI == 0, "tile does not divide over the workgroup");
@@ -1447,6 +1447,18 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const double *__restr
 #define TF_EVAL_CAP256_MAXK 112
 #endif
 static int cap_for_k(int k) { return k <= TF_EVAL_CAP256_MAXK ? 256 : (k <= 240 ? 512 : 0); }
+// The second kernel (bf16, padded d = 128) keeps lists of 384 entries for k between 65 and 112: with a hundred survivors a
+// list of 256 has room for some fifty appends per half before the next compaction, a list of 384 for more than a hundred
+// (half as many compactions for slightly looser thresholds; measured -1 % / -3 % at 2M items, k = 100; its sort buffers
+// still fit beside two tiles of 256 items, which lists of 512 do not).  0 = lists of 256 there too.
+#ifndef TF_EVAL_CAP384
+#define TF_EVAL_CAP384 1
+#endif
+static int cap_for(int k, bool bf16, int D)
+{
+    if (TF_EVAL_CAP384 && TF_EVAL_PP && bf16 && D == 128 && k > 64 && k <= 112) return 384;
+    return cap_for_k(k);
+}
 
 // the dynamic-LDS limit is a per-device attribute of a kernel: set once on every device an instantiation runs on
 // (bit = device ordinal; devices beyond 63 set it on every launch)
@@ -1558,12 +1570,12 @@ static inline int merge_group(int k) { return 2048 / k; }
 
 static int plan_score(const float *d_Q, int d, int64_t item_lo, int64_t item_hi, int64_t n, int k, int score_mode, ScorePlan *p)
 {
-    p->CAP = cap_for_k(k);
-    TF_REQUIRE(p->CAP != 0, TFREC_EUNSUP, "top-k above 240 is not supported (k=%d)", k);
+    TF_REQUIRE(cap_for_k(k) != 0, TFREC_EUNSUP, "top-k above 240 is not supported (k=%d)", k);
     p->D = pad_dim(d, score_mode);
     TF_REQUIRE(p->D != 0, TFREC_EUNSUP, "factor size d=%d is not supported for this score mode", d);
     p->n_items = item_hi - item_lo;
     p->bf16 = score_mode == TFREC_SCORE_BF16;
+    p->CAP = cap_for(k, p->bf16, p->D);
     p->direct = !p->bf16 && d == p->D && (((uintptr_t)d_Q) & 15u) == 0;
     p->TI = 768;      // a multiple of every ScoreGeom::TI
     p->chunk = 1 << 20;          // users per launch: bounds the candidate-list workspace
@@ -1666,6 +1678,9 @@ static int score_topk_impl(tfrec_ctx *ctx, const float *d_P, const float *d_Q, c
         const int64_t ub = 128;
         const int user_blocks = (int)((nn + ub - 1) / ub);
         if (CAP == 256) TF_TRY(launch_score_cap<256>(ctx, a, D, score_mode, user_blocks, splits));
+#if TF_EVAL_CAP384 && TF_EVAL_PP
+        else if (CAP == 384) TF_TRY((launch_score<128, true, 384>(ctx, a, user_blocks, splits)));      // (cap_for: bf16, D = 128 only)
+#endif
         else TF_TRY(launch_score_cap<512>(ctx, a, D, score_mode, user_blocks, splits));
         if (splits > 1 && !pl.part2_bytes) {
             TF_TRY(merge_lists(ctx, part_ids, part_sc, splits, nn, k, d_out_ids + (size_t)u0 * k, d_out_scores + (size_t)u0 * k));
@@ -1866,8 +1881,9 @@ extern "C" int tfrec_rank_metrics(tfrec_ctx *ctx, const int32_t *d_ids, const in
 // score buffers, metric rows); the prepared item table comes on top for bf16 / padded scoring
 size_t tfrec_eval_scratch_bytes(int64_t n, int k)
 {
-    const int CAP = cap_for_k(k);
+    int CAP = cap_for_k(k);
     if (!CAP) return 0;
+    if (cap_for(k, true, 128) > CAP) CAP = cap_for(k, true, 128);      // whatever score mode and factor size the call will have
     const int64_t nc = n < (1 << 20) ? n : (1 << 20);
     return 2 * tf_align(4 * (size_t)n * k) + tf_align(sizeof(uint64_t) * (size_t)nc * CAP) + metrics_host_need(n, k, 0, false) + 8192;
 }

@@ -71,6 +71,7 @@ WHAT = {
     "trig32": "shipped kernels, a list half compacted when fewer than 32 (instead of 16) entries are free -- `-DTF_EVAL_TRIGGER_SLACK=32`",
     "trig48": "the same, 48",
     "trig64": "the same, 64",
+    "cap384": "second kernel with candidate lists of 384 entries for k = 65...112 (tiles of 256 items still fit): shipped after this log",
     "pp64": "glds, and the second kernel for d=64 as well (four matrix instructions per phase, tiles of 384 items) -- `-DTF_EVAL_PP=2`",
 }
 
