@@ -48,10 +48,13 @@ def short(name):
 
 def eval_section(d1, d2, d3):
     """Matrix-pipe utilisation of score_topk_kernel from the SQ counters (sums over all dispatches of the passes)."""
+    names = set()
+
     def sums(d):
         a, dur, seen = collections.defaultdict(float), 0, set()
         for r in csv.DictReader(open(find(d, "counter_collection.csv"))):
             if "score_topk" in r["Kernel_Name"] and "kernel" in r["Kernel_Name"]:
+                names.add(r["Kernel_Name"].replace("void ", "").split("(")[0])
                 a[r["Counter_Name"]] += float(r["Counter_Value"])
                 if r["Dispatch_Id"] not in seen:
                     seen.add(r["Dispatch_Id"])
@@ -68,7 +71,7 @@ def eval_section(d1, d2, d3):
     flops = 2.0 * users * items * d * n1
     out = ["## Scoring kernel: matrix-pipe utilisation (PMC)", "",
            "`tools/eval_probe.py --users 262144 --I 2000000 --d 128 --k 100 --model random --mode bf16` (independent factors) under",
-           "`rocprofv3 --pmc` in three passes (`tools/collect_profiles.sh`); sums over the %d dispatches of the bf16 d=128 scoring kernel (`score_topk_pp_kernel<128, 256>`) in a pass." % n1, "",
+           "`rocprofv3 --pmc` in three passes (`tools/collect_profiles.sh`); sums over the %d dispatches of the bf16 d=128 scoring kernel (`%s`) in a pass." % (n1, ", ".join(sorted(names))), "",
            "| quantity | value |", "|---|---|",
            "| kernel time per dispatch | %.1f ms |" % (t1 / n1 * 1e3),
            "| clock held (GRBM_GUI_ACTIVE / 8 XCDs / time) | %.2f GHz |" % clock,
@@ -84,7 +87,7 @@ def eval_section(d1, d2, d3):
                100 * a1["SQ_WAIT_ANY"] / a1["SQ_WAVE_CYCLES"], 100 * a1["SQ_WAIT_INST_ANY"] / a1["SQ_WAVE_CYCLES"]),
            "| vector instructions per matrix instruction | %.1f |" % (a1["SQ_INSTS_VALU"] / a3["SQ_INSTS_MFMA"] * n3 / n1), ""]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    json.dump({"kernel": "score_topk_pp_kernel<128, 256>", "workload": "262144 users x 2M items, d=128, k=100, independent factors",
+    json.dump({"kernel": ", ".join(sorted(names)), "workload": "262144 users x 2M items, d=128, k=100, independent factors",
                "mfma_busy_frac": busy, "clock_ghz": clock, "tflops": flops / t1 / 1e12,
                "source": "rocprofv3 --pmc passes of tools/collect_profiles.sh"},
               open(os.path.join(root, "profiles", "pmc_mfma.json"), "w"), indent=1)
