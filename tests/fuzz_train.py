@@ -25,6 +25,9 @@ def one(dev, rng, case):
     B = int(rng.choice([rng.integers(1, 600), edge + rng.integers(-1, 2), rng.integers(600, 20000), rng.integers(100000, 400000)]))
     if B * d > 3e7 or (U + I) * d > 3e7:
         d = 16
+    # (summed gradients of more than some ten thousand occurrences of one row take the parameters to 1e3 ... 1e5 in one step;
+    # the second step then magnifies the first one's float32 rounding beyond any fixed tolerance: three such cases in 7200)
+    B = int(min(B, 20000 * min(U, I)))
     kind = str(rng.choice(["uniform", "zipf", "hot"]))
     path = str(rng.choice(["plain", "versioned", "prepared"]))
     P = rng.uniform(-0.3, 0.3, (U, d)).astype(np.float32)
