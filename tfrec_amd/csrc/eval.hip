@@ -613,6 +613,7 @@ struct ScoreGeom {
 #ifndef TF_EVAL_TRIGGER_SLACK
 #define TF_EVAL_TRIGGER_SLACK 16
 #endif
+static_assert(TF_EVAL_TRIGGER_SLACK >= 16, "a lane may append all sixteen items of a block before the next check");
 
 template <int D, bool BF16, int CAP>
 __global__ __launch_bounds__((64 * ScoreWave<D, BF16, CAP>::NW)) void score_topk_kernel(ScoreArgs a)
